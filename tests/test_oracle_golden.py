@@ -1,0 +1,77 @@
+"""Pin the CPU oracle (oracle/spacegym_oracle.c) against golden vectors captured from the
+unmodified reference (tools/gen_golden.py -> tests/golden/step_*.npz).
+
+The fixtures hold fp32-representable inputs and the fp64 outputs of the reference's
+SpaceshipEnv.step (spaceship_env.py:68-78): state', observation, reward, done, goal-hit, plus
+scipy diagnostics (accepted RK45 steps, RHS evaluations, terminal event index and time).
+`core_state1/core_done` were produced by `dynamic_model.make_step` imported with numpy+scipy only
+(no gym namespace shim) and are bitwise equal to the env-layer outputs.
+"""
+import numpy as np
+import pytest
+
+from conftest import FAMILIES
+from oracle import Oracle
+
+# fp64 restatement vs fp64 reference: differences are summation-order / libm ulps only
+TOL_STATE = 1e-12
+TOL_OBS = 1e-12
+TOL_REWARD = 1e-10  # reward amplifies position differences x500..x1000 (goal.py:147-152)
+TOL_T_EVENT = 1e-13
+
+
+@pytest.mark.parametrize("fam", list(FAMILIES))
+def test_oracle_matches_reference_golden(fam, golden_steps):
+    d = golden_steps[fam]
+    o = Oracle(FAMILIES[fam])
+    r = o.step(d["state0"], d["action"], d.get("planets"), d.get("goal"), with_diag=True)
+    assert np.array_equal(r["done"], d["done"])
+    assert np.array_equal(r["goal_hit"], d["goal_changed"])
+    assert np.abs(r["state1"] - d["state1"]).max() <= TOL_STATE
+    assert np.abs(r["state1"] - d["core_state1"]).max() <= TOL_STATE  # no-shim make_step fixtures
+    assert np.array_equal(r["done"], d["core_done"])
+    assert np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
+    assert np.abs(r["reward"] - d["reward"]).max() <= TOL_REWARD
+    # same adaptive-step decisions as scipy's RK45 controller and the same terminal event
+    assert np.array_equal(r["diag"]["n_rk_steps"], d["n_rk_steps"])
+    assert np.array_equal(r["diag"]["nfev"], d["nfev"])
+    assert np.array_equal(r["diag"]["event_index"], d["event_index"])
+    term = d["done"] == 1
+    assert np.abs(r["diag"]["t_event"][term] - d["t_event"][term]).max() <= TOL_T_EVENT
+
+
+@pytest.mark.parametrize("fam", list(FAMILIES))
+def test_golden_covers_the_edge_cases(fam, golden_steps):
+    """The fixture set itself: terminal steps through every event kind, goal hits, 1- and 2-step RK45 runs."""
+    d = golden_steps[fam]
+    n = int(d["const_n_planets"])
+    ev = d["event_index"][d["done"] == 1]
+    if fam.startswith("goal"):
+        assert set(range(n + 2)) <= set(ev.tolist())  # every planet, world_max, world_min
+        assert d["goal_changed"].sum() >= 50
+        assert ((d["done"] == 1) & (d["goal_changed"] == 1)).sum() >= 0
+    else:
+        assert {0, 1} <= set(ev.tolist())  # central planet and border circle
+    assert {1, 2} <= set(d["n_rk_steps"].tolist())
+    assert (d["done"] == 1).sum() >= 400 and (d["done"] == 0).sum() >= 1200
+    # inputs are fp32-representable so the fp32 engine sees exactly what the reference saw
+    for k in ("state0", "planets", "goal"):
+        if k in d:
+            assert np.array_equal(d[k], d[k].astype(np.float32).astype(np.float64))
+
+
+def test_invariants_of_reference_outputs(golden_steps):
+    """omega == float32(5*a1); theta in [0, 2pi); terminal state sits on a boundary."""
+    for fam, d in golden_steps.items():
+        s1 = d["state1"]
+        assert np.array_equal(s1[:, 5], (d["action"][:, 1] * np.float32(5.0)).astype(np.float64))
+        assert (s1[:, 2] >= 0).all() and (s1[:, 2] < 2 * np.pi).all()
+        o = Oracle(FAMILIES[fam])
+        half = o.params.world_size / 2
+        term = d["done"] == 1
+        n = o.n_planets
+        planets = d["planets"] if "planets" in d else np.zeros((len(s1), n, 2))
+        dist = np.linalg.norm(planets - s1[:, None, :2], axis=2) - np.array(o.params.planet_radius[:n])
+        wall = half - np.abs(s1[:, :2]).max(axis=1)
+        g = np.minimum(np.abs(dist).min(axis=1), np.abs(wall))
+        assert g[term].max() < 1e-9
