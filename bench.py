@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the batched step() at batch = 65536 per GPU on GoalContinuous3P-v0
+(BASELINE.json `metric`, configs[2]); one process per GPU, weak scaling, no data-path collective.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one launch of the fused step kernel over the whole per-GPU batch (integrate + events + observation +
+reward + goal resample + TimeLimit + auto-reset).  Inputs (a ring of U(-1,1) action blocks) are resident in HBM
+before the timed region; outputs go to a [steps, B, ...] rollout buffer in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(env_id):
+    """fp32 SoA, each live field moved once; reset / goal-resample traffic excluded."""
+    from space_gym_amd.registration import ENV_SPECS
+    s = ENV_SPECS[env_id]
+    return 113 + 16 * s["n_planets"] if s["family"] == "goal" else 109
+
+
+def cpu_baseline(env_id, batch, budget_s=12.0):
+    """The fp64 CPU oracle (oracle/, a restatement of the reference's NumPy/scipy path pinned to its golden vectors)
+    on the same workload, all host cores of this box, bounded sample.  Reported beside the GPU number, never as it."""
+    import numpy as np
+    from oracle import Oracle
+    cores = len(os.sched_getaffinity(0))
+    o = Oracle(env_id, threads=cores)
+    n = min(batch, 65536)
+    envs, _ = o.vec_reset(n, seed=0)
+    rng = np.random.default_rng(1)
+    acts = [rng.uniform(-1, 1, size=(n, 2)).astype(np.float32) for _ in range(8)]
+    for i in range(3):  # warm-up
+        o.vec_step(envs, acts[i], seed=0)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        o.vec_step(envs, acts[steps % 8], seed=0)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} vector steps of {n} envs ({env_id}, random U(-1,1) actions, auto-reset on), "
+                      f"{dt:.1f} s, OpenMP over {cores} threads, fp64 RK45 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--env", default="GoalContinuous3P-v0")
+    ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--action-ring", type=int, default=64, help="distinct pre-generated action blocks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time a per-step RCCL gather of (obs,reward,done) to rank 0")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import space_gym_amd as sg
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, K, W = args.batch, args.steps, args.warmup
+    env = sg.make_vec(args.env, B, device=local_rank, seed=args.seed, env_index_base=rank * B)
+    D = env.obs_dim
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    ring = max(1, min(args.action_ring, max(K, W)))
+    actions = torch.rand((ring, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+    nbuf = max(K, W, 1)
+    # rollout buffers in HBM (3.9 GB of observations at K=1000, B=65536, D=15)
+    act_seq = actions.repeat((nbuf + ring - 1) // ring, 1, 1)[:nbuf].contiguous()
+    obs = torch.empty((nbuf, B, D), device=dev, dtype=torch.float32)
+    rew = torch.empty((nbuf, B), device=dev, dtype=torch.float32)
+    done = torch.empty((nbuf, B), device=dev, dtype=torch.uint8)
+    trunc = torch.empty((nbuf, B), device=dev, dtype=torch.uint8)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+
+    env.reset_torch()
+    if W > 0:
+        env.rollout_torch(act_seq[:W], obs[:W], rew[:W], done[:W], trunc[:W])
+    sync_all()
+
+    # ---- timed region: exactly K steps, kernel durations taken from start/stop events on each dispatch
+    timing = not args.no_kernel_timing
+    env.set_profiling(timing)
+    sync_all()
+    t0 = time.perf_counter()
+    env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+    sync_all()
+    dt = time.perf_counter() - t0
+    launches, kern_ms, kmin, kmax = env.get_profile() if timing else (0, 0.0, 0.0, 0.0)
+    env.set_profiling(False)
+
+    # ---- untimed A/B: the same K steps without per-dispatch events, to show what the instrumentation costs
+    dt_plain = None
+    if timing:
+        sync_all()
+        t1 = time.perf_counter()
+        env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+        sync_all()
+        dt_plain = time.perf_counter() - t1
+
+    gather_ms = None
+    if args.gather and world > 1:
+        packed = torch.empty((B, D + 2), device=dev, dtype=torch.float32)
+        bufs = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+        sync_all()
+        t2 = time.perf_counter()
+        for t in range(K):
+            env.rollout_torch(act_seq[t:t + 1], obs[t:t + 1], rew[t:t + 1], done[t:t + 1], trunc[t:t + 1])
+            packed[:, :D] = obs[t]; packed[:, D] = rew[t]; packed[:, D + 1] = done[t].float()
+            dist.gather(packed, bufs, dst=0)
+        sync_all()
+        gather_ms = (time.perf_counter() - t2) * 1e3 / K
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    n_done = done[:K].sum(dtype=torch.float64).reshape(1)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n_done, op=dist.ReduceOp.SUM)
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        bytes_per = algorithmic_bytes_per_env_step(args.env)
+        out = {
+            "metric": "env-steps/sec at batch=65536, GoalContinuous3P-v0, 1/2/4/8 MI355X",
+            "value": world * B * K / dt_max, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.env}, batch={B} per GPU, i.i.d. U(-1,1) actions resident in HBM "
+                                   f"(ring of {ring} blocks), auto-reset on (termination or 500-step truncation), "
+                                   f"one fused step-kernel launch per step via sg_rollout_device, outputs to a "
+                                   f"[steps, B, ...] rollout buffer in HBM",
+                       "env_id": args.env, "batch_per_gpu": B, "global_batch": world * B, "obs_dim": D,
+                       "parallelism": f"env-sharded x{world}, no data-path collective",
+                       "episodes_finished_per_step": float(n_done.item()) / K},
+        }
+        if timing and launches:
+            avg_us = kern_ms * 1e3 / launches
+            achieved = B * bytes_per / (avg_us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "goal_step_kernel<3>" if args.env == "GoalContinuous3P-v0" else "step kernel",
+                               "kernel_avg_us": avg_us, "kernel_min_us": kmin * 1e3, "kernel_max_us": kmax * 1e3,
+                               "launches": launches, "algorithmic_bytes_per_env_step": bytes_per,
+                               "algorithmic_bytes_per_launch": B * bytes_per}
+            out["value_without_dispatch_events"] = world * B * K / dt_plain if dt_plain else None
+        if gather_ms is not None:
+            out["ms_per_step_with_rccl_gather"] = gather_ms
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.env, B)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+/*
+ * spacegym.h -- C ABI of the MI355X batched Space-Gym step engine (libspacegym_hip.so).
+ *
+ * The reference (MIMUW-RL/space-gym) has no FFI; the seam this library sits behind is its gym.Env
+ * protocol.  Each entry point names the reference interface it replaces (paths under the reference
+ * repo root).  One handle advances `num_envs` independent (ship, planets, goal/orbit) instances in
+ * lock-step on one GPU; envs never interact (gym_space/dynamic_model.py:145-165 sums only an env's
+ * own planets), so a multi-GPU job is one handle per device with disjoint `env_index_base`.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SG_ERR_* code; sg_last_error() gives the text;
+ *   - plain pointers and sizes only; "host" pointers are ordinary memory, "device" pointers are HIP
+ *     device memory on the handle's GPU, owned by the caller;
+ *   - no allocation, no host synchronisation and no host<->device copy inside the *_device calls:
+ *     they only enqueue kernels on the given stream (hipGraph-capturable);
+ *   - a handle is not thread-safe; independent handles are.
+ *   - observations/rewards are float32 (the reference returns float64; parity tolerance in DESIGN.md).
+ */
+#ifndef SPACEGYM_H
+#define SPACEGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_OK 0
+#define SG_ERR_INVALID -1   /* bad argument / unknown env id */
+#define SG_ERR_HIP -2       /* HIP runtime error (message has the HIP text) */
+#define SG_ERR_NO_DEVICE -3 /* no usable GPU: the engine has no CPU path */
+
+typedef struct sg_env sg_env; /* opaque handle */
+
+typedef struct sg_config {
+    /* Registered id, as in gym_space/__init__.py:26-146: GoalContinuous{2,3,4}P-v0,
+     * Kepler{CircleOrbit,EllipseEasy,EllipseHard,RandomOrbits}-v0. */
+    char env_id[64];
+    int64_t num_envs;          /* batch on this device */
+    uint64_t seed;             /* SpaceshipEnv.seed, spaceship_env.py:92-94 / goal.py:74-77 */
+    uint32_t env_index_base;   /* global index of local env 0; the RNG is keyed by the global index */
+    int32_t max_episode_steps; /* 0 -> the id's registered value (500): gym TimeLimit, __init__.py:29 */
+    int32_t auto_reset;        /* 1: finished envs restart inside step (VectorEnv semantics); 0: they keep
+                                  their terminal state, like a bare reference env */
+} sg_config;
+
+/* GoalContinuousEnv(**kwargs) / KeplerContinuousEnv(**kwargs) construction (goal.py:18-72,
+ * kepler.py:189-231) for num_envs instances on GPU `device`. */
+int sg_create(const sg_config *cfg, int device, sg_env **out);
+int sg_destroy(sg_env *env);
+const char *sg_last_error(const sg_env *env); /* env may be NULL: last error of a failed sg_create */
+
+int64_t sg_num_envs(const sg_env *env);
+int32_t sg_obs_dim(const sg_env *env);      /* 7 + 2N + 2 (Goal, spaceship_env.py:102-111,124-131); 10 (Kepler, kepler.py:158-187) */
+int32_t sg_num_planets(const sg_env *env);  /* planets with a per-env position: N (Goal), 0 (Kepler) */
+
+/* SpaceshipEnv.seed (spaceship_env.py:92-94): takes effect at the next reset. */
+int sg_seed(sg_env *env, uint64_t seed);
+int sg_set_auto_reset(sg_env *env, int32_t on);
+
+/* SpaceshipEnv.reset (spaceship_env.py:59-66) for every env; obs is float32 [num_envs, obs_dim]. */
+int sg_reset(sg_env *env, float *obs_host);
+int sg_reset_device(sg_env *env, float *obs_dev, void *hip_stream);
+
+/* SpaceshipEnv.step (spaceship_env.py:68-78) for every env, plus what gym.wrappers.TimeLimit and a
+ * VectorEnv add around it (elapsed-step counter, truncation, auto-reset).
+ *   actions     float32 [num_envs, 2] raw policy output in [-1, 1]^2 (clamped into range on the device;
+ *               the reference asserts, spaceship_env.py:71)
+ *   obs         float32 [num_envs, obs_dim]; for a finished env (auto_reset on) the first observation of
+ *               its next episode
+ *   reward      float32 [num_envs]
+ *   done        uint8   [num_envs]  terminal event or truncation
+ *   truncated   uint8   [num_envs]  elapsed == max_episode_steps without a terminal event ("TimeLimit.truncated")
+ *   terminal_obs  optional float32 [num_envs, obs_dim]; rows of finished envs receive the last observation of
+ *               the episode that ended, other rows are left untouched.  May be NULL. */
+int sg_step(sg_env *env, const float *actions_host, float *obs_host, float *reward_host, uint8_t *done_host,
+            uint8_t *truncated_host, float *terminal_obs_host);
+int sg_step_device(sg_env *env, const float *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+                   uint8_t *truncated_dev, float *terminal_obs_dev, void *hip_stream);
+
+/* `n_steps` consecutive steps enqueued back to back: actions [n_steps, num_envs, 2], obs [n_steps, num_envs, obs_dim],
+ * reward/done/truncated [n_steps, num_envs].  Equivalent to n_steps calls of sg_step_device. */
+int sg_rollout_device(sg_env *env, int32_t n_steps, const float *actions_dev, float *obs_dev, float *reward_dev,
+                      uint8_t *done_dev, uint8_t *truncated_dev, void *hip_stream);
+
+/* State access (the reference exposes env._ship_state._state_vec, planet.center_pos, env.goal_pos as plain
+ * attributes; golden-vector injection needs the same).  Host arrays, any may be NULL to skip:
+ *   ship    float32 [num_envs, 6]   x, y, theta, vx, vy, omega   (dynamic_model.py:40)
+ *   planets float32 [num_envs, N, 2]                              (Goal only)
+ *   goal    float32 [num_envs, 2]   Goal: goal position; KeplerRandomOrbits: (ref_orbit_angle, ref_orbit_eccentricity)
+ *   elapsed int32   [num_envs]      steps taken in the current episode */
+int sg_get_state(sg_env *env, float *ship, float *planets, float *goal, int32_t *elapsed);
+int sg_set_state(sg_env *env, const float *ship, const float *planets, const float *goal, const int32_t *elapsed);
+
+/* Measurement aid (no reference counterpart): with profiling on, each step-kernel launch carries start/stop events
+ * that timestamp the dispatch itself; sg_get_profile returns and clears the durations recorded so far (milliseconds).
+ * The caller synchronises the stream(s) first. */
+int sg_set_profiling(sg_env *env, int32_t on);
+int sg_get_profile(sg_env *env, int64_t *launches, double *total_ms, double *min_ms, double *max_ms);
+
+/* The HIP stream the host-buffer calls run on (hipStream_t), for callers that want to order work after it. */
+void *sg_stream(const sg_env *env);
+
+const char *sg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

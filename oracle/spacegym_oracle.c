@@ -696,7 +696,8 @@ void sgo_env_reset(const sgo_params *p, uint64_t seed, uint32_t env_id, sgo_env_
         double ship_radius = p->planet_radius[0] / 2; /* hexagonal_tiling.py:48 */
         disc_in_tile(p, &L, tiles[0], ship_radius, xo_next(&g), e->state); /* :92-93 */
         for (int j = 0; j < N; j++) disc_in_tile(p, &L, tiles[j + 1], p->planet_radius[j], xo_next(&g), e->planets_xy + 2 * j);
-        uint32_t gw[4] = {flags >> 24, xo_next(&g), xo_next(&g), xo_next(&g)};
+        uint32_t gw[4];
+        gw[0] = flags >> 24; gw[1] = xo_next(&g); gw[2] = xo_next(&g); gw[3] = xo_next(&g);
         e->goal_tile = -1;
         choose_goal(p, &L, e, 1, gw); /* goal.py:138 */
         /* goal.py:140-145 */

@@ -1,0 +1,69 @@
+"""ctypes binding of libspacegym_hip.so (include/spacegym.h).  There is no CPU path: if the HIP library is
+missing or no GPU is visible, creating an engine raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspacegym_hip.so")
+_lib = None
+
+
+class SgConfig(C.Structure):
+    _fields_ = [("env_id", C.c_char * 64), ("num_envs", C.c_int64), ("seed", C.c_uint64),
+                ("env_index_base", C.c_uint32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+# every symbol include/spacegym.h declares: (restype, argtypes)
+_fp, _u8p, _i32p, _vp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_void_p
+SYMBOLS = {
+    "sg_create": (C.c_int, [C.POINTER(SgConfig), C.c_int, C.POINTER(_vp)]),
+    "sg_destroy": (C.c_int, [_vp]),
+    "sg_last_error": (C.c_char_p, [_vp]),
+    "sg_num_envs": (C.c_int64, [_vp]),
+    "sg_obs_dim": (C.c_int32, [_vp]),
+    "sg_num_planets": (C.c_int32, [_vp]),
+    "sg_seed": (C.c_int, [_vp, C.c_uint64]),
+    "sg_set_auto_reset": (C.c_int, [_vp, C.c_int32]),
+    "sg_reset": (C.c_int, [_vp, _vp]),
+    "sg_reset_device": (C.c_int, [_vp, _vp, _vp]),
+    "sg_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sg_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sg_rollout_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sg_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sg_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sg_set_profiling": (C.c_int, [_vp, C.c_int32]),
+    "sg_get_profile": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sg_stream": (_vp, [_vp]),
+    "sg_version": (C.c_char_p, []),
+}
+
+
+def load():
+    """Load the HIP library once.  torch (if installed) is imported first so that both use the same HIP runtime
+    (torch bundles libamdhip64 under the same SONAME) and device pointers can be shared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} not found: build it with `python -m space_gym_amd.build` "
+                          "(hipcc, gfx950). The engine is HIP-only; there is no CPU fallback.")
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(lib, handle, rc, what):
+    if rc != 0:
+        msg = lib.sg_last_error(handle)
+        raise NativeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,834 @@
+/*
+ * sg_device.hpp -- per-environment device math of the Space-Gym engine (fp32, one env per lane).
+ *
+ * Everything here is straight-line per-lane code with no memory traffic: the kernels in
+ * sg_kernels.hip load one env into registers, call these functions, and store the result.
+ *
+ * What is restated, and from where (paths under /root/reference):
+ *   - RHS            gym_space/dynamic_model.py:129-176, gym_space/helpers.py:22-35
+ *   - integrator     dynamic_model.py:112-118 -> scipy.integrate.solve_ivp(method="RK45"): the SAME
+ *                    Dormand-Prince 5(4) adaptive controller (initial-step rule, error norm,
+ *                    accept/reject, step factor) in fp32, so that the engine follows the reference
+ *                    also where RK45's own truncation error is visible (fast grazes near a planet).
+ *   - events         dynamic_model.py:183-217 with scipy's sign-change detection per accepted RK
+ *                    step (ivp.py:133-156) and a root on the same 4th-order dense output
+ *                    (rk.py RkDenseOutput) -- located with a bracketed Illinois iteration.
+ *   - observation    gym_space/envs/spaceship_env.py:113-140, kepler.py:172-187
+ *   - rewards        goal.py:147-158,160-164,204-227; kepler.py:43-156 (fp64 epilogue)
+ *   - reset sampler  hexagonal_tiling.py:53-158, goal.py:133-145, kepler.py:233-267 on a counter-based
+ *                    RNG (Philox4x32-10 -> xoshiro128++), see DESIGN.md.
+ *
+ * Heading: with Steering.velocity (every registered id) the RHS pins omega = 5*a1 for the whole
+ * step (dynamic_model.py:138-141), so theta(t) = theta0 + omega*t exactly and only (x, y, vx, vy)
+ * are integrated; the theta/omega components still enter RK45's norms exactly as in scipy.
+ *
+ * The same source is compiled by g++ into a test-only host twin (tests/host_twin) so the fp32
+ * numerics can be checked against the oracle without a GPU.  It is never used by the product.
+ */
+#ifndef SG_DEVICE_HPP
+#define SG_DEVICE_HPP
+
+#include <math.h>
+#include <stdint.h>
+
+#include "sg_config.h"
+
+#if defined(__HIPCC__)
+#define SG_FN __device__ __forceinline__
+#define SG_MFN __device__ __forceinline__
+#else
+#define SG_FN static inline
+#define SG_MFN inline
+#endif
+
+namespace sg {
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+SG_FN float rsq(float x) { return __builtin_amdgcn_rsqf(x); }      // v_rsq_f32, 1 ulp
+SG_FN float rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
+SG_FN float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
+SG_FN float flog2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+SG_FN float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+#else
+SG_FN float rsq(float x) { return 1.0f / sqrtf(x); }
+SG_FN float rcp(float x) { return 1.0f / x; }
+SG_FN float fsqrt(float x) { return sqrtf(x); }
+SG_FN float flog2(float x) { return log2f(x); }
+SG_FN float fexp2(float x) { return exp2f(x); }
+#endif
+
+constexpr float kTwoPi = 6.283185307179586f;
+
+// sin/cos for |r| <= pi/4 (minimax polynomials, ~1 ulp)
+SG_FN void sincos_poly(float r, float &s, float &c) {
+    float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    s = fmaf(ps * z, r, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+}
+
+// sin/cos for |a| < ~1e3 with a two-term Cody-Waite reduction to [-pi/4, pi/4]
+SG_FN void sincos_acc(float a, float &s, float &c) {
+    float k = rintf(a * 0.6366197723675814f);
+    float r = fmaf(-k, 1.57079637050628662109375f, a);
+    r = fmaf(-k, -4.37113900018624283e-8f, r);
+    float sr, cr;
+    sincos_poly(r, sr, cr);
+    int q = (int)k & 3;
+    float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s1 : s1;
+    c = ((q + 1) & 2) ? -c1 : c1;
+}
+
+SG_FN float wrap_two_pi(float th) {  // dynamic_model.py:179-180 (Python %: result in [0, 2pi))
+    th = th - kTwoPi * floorf(th * (1.0f / kTwoPi));
+    th = (th < 0.0f) ? th + kTwoPi : th;
+    return (th >= kTwoPi) ? th - kTwoPi : th;
+}
+
+SG_FN double rsqrt_f64(double x) {  // fp32 seed + one Newton step in fp64: ~2e-14 relative
+    double y = (double)rsq((float)x);
+    return y * (1.5 - 0.5 * x * y * y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dormand-Prince 5(4) tableau and Shampine's dense output: scipy/integrate/_ivp/rk.py class RK45
+// ------------------------------------------------------------------------------------------------
+constexpr float C2 = 1.0f / 5, C3 = 3.0f / 10, C4 = 4.0f / 5, C5 = 8.0f / 9;
+constexpr float A21 = 1.0f / 5;
+constexpr float A31 = 3.0f / 40, A32 = 9.0f / 40;
+constexpr float A41 = 44.0f / 45, A42 = -56.0f / 15, A43 = 32.0f / 9;
+constexpr float A51 = 19372.0f / 6561, A52 = -25360.0f / 2187, A53 = 64448.0f / 6561, A54 = -212.0f / 729;
+constexpr float A61 = 9017.0f / 3168, A62 = -355.0f / 33, A63 = 46732.0f / 5247, A64 = 49.0f / 176,
+                A65 = -5103.0f / 18656;
+constexpr float B1 = 35.0f / 384, B3 = 500.0f / 1113, B4 = 125.0f / 192, B5 = -2187.0f / 6784, B6 = 11.0f / 84;
+// Position increment in Nystrom form: sum_j B_j (v + h sum_l A_jl a_l) = v + h sum_l beta_l a_l, beta_l = sum_j B_j A_jl
+// (sum beta = 1/2).  Algebraically the same DP5 step; h*v is then formed once, in fp64, for the reward path.
+constexpr float BETA1 = 35.0f / 384, BETA3 = 50.0f / 159, BETA4 = 25.0f / 192, BETA5 = -243.0f / 6784;
+// E sums to zero, so sum_j E_j K_j == sum_{j>=1} E_j (K_j - K_0): evaluated on differences in fp32
+constexpr float E3 = 71.0f / 16695, E4 = -71.0f / 1920, E5 = 17253.0f / 339200, E6 = -22.0f / 525, E7 = 1.0f / 40;
+// P[:, 1..3]; each column sums to zero over the stages, so Q_j = sum_{s>=2} P[s][j] (K_s - K_0)
+constexpr float P31 = (float)(131558114200.0 / 32700410799.0), P32 = (float)(-68118460800.0 / 10900136933.0),
+                P33 = (float)(87487479700.0 / 32700410799.0);
+constexpr float P41 = (float)(-1754552775.0 / 470086768.0), P42 = (float)(14199869525.0 / 1410260304.0),
+                P43 = (float)(-10690763975.0 / 1880347072.0);
+constexpr float P51 = (float)(127303824393.0 / 49829197408.0), P52 = (float)(-318862633887.0 / 49829197408.0),
+                P53 = (float)(701980252875.0 / 199316789632.0);
+constexpr float P61 = (float)(-282668133.0 / 205662961.0), P62 = (float)(2019193451.0 / 616988883.0),
+                P63 = (float)(-1453857185.0 / 822651844.0);
+constexpr float P71 = (float)(40617522.0 / 29380423.0), P72 = (float)(-110615467.0 / 29380423.0),
+                P73 = (float)(69997945.0 / 29380423.0);
+constexpr float kRtol = 1e-3f, kAtol = 1e-6f;  // solve_ivp defaults (dynamic_model.py:112-118 passes none)
+constexpr float kSafety = 0.9f, kMinFactor = 0.2f, kMaxFactor = 10.0f;  // rk.py:8-11
+constexpr int kMaxRkAttempts = 12;  // bound on accepted+rejected RK steps per env-step (reference mean: 1.19)
+constexpr int kRootIters = 6;   // fp32 Illinois iterations before the fp64 Newton polish
+
+struct StepResult {
+    double dXd, dYd; // displacement from the start position, fp64 accumulation of h v + h^2 sum_l beta_l a_l
+    float dX, dY;    // the same rounded to fp32
+    float vx, vy;
+    float t;         // time actually advanced: step_size, or the event time
+    int done;        // a terminal event fired (dynamic_model.py:124)
+    int event;       // circle index, NC = world_max, NC + 1 = world_min
+    int n_rk;        // accepted RK45 steps (diagnostics)
+};
+
+// RHS acceleration at displacement (X, Y) from the start position and time t since the step started:
+// thrust -(cos, sin)(theta0 + omega t) * F  (dynamic_model.py:168-176) + sum of planet pulls (helpers.py:22-35).
+// cqx/cqy are circle centres relative to the start position; the first NG circles gravitate.
+template <int NC, int NG>
+SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float F, float C0, float S0, float om,
+                 float t, float X, float Y, float &ax, float &ay) {
+    float sd, cd;
+    sincos_poly(om * t, sd, cd);  // |omega t| <= 5 * 0.07
+    float c = fmaf(C0, cd, -S0 * sd), s = fmaf(S0, cd, C0 * sd);
+    ax = -c * F;
+    ay = -s * F;
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        float dx = cqx[j] - X, dy = cqy[j] - Y;
+        float r2 = fmaf(dx, dx, dy * dy);
+        float ir = rsq(r2);
+        float w = gm * ir * ir * ir;
+        ax = fmaf(dx, w, ax);
+        ay = fmaf(dy, w, ay);
+    }
+}
+
+// One env-step of dynamic_model.make_step (dynamic_model.py:94-125) in fp32.
+//   NC circles with radii cR (Goal: the planets; Kepler: planet + border, both centred on the origin),
+//   the first NG of them gravitate; WALLS adds the world_max / world_min events (dynamic_model.py:196-208).
+//   The angular-velocity event (:210-212, limit 6) cannot fire: |omega| = |5 a1| <= 5 for actions in [-1, 1].
+template <int NC, int NG, bool WALLS>
+SG_FN void make_step(float h_total, float half_world, float gm, float F, float om, float x0, float y0, float th0,
+                     float vx0, float vy0, const float (&cax)[NC], const float (&cay)[NC], const float (&cR)[NC],
+                     const double (&cRd)[NC], StepResult &o) {
+    // circle centres relative to the start position (fp32 working copy; the fp64 root polish uses cax/cay)
+    float cqx[NC], cqy[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x0; cqy[k] = cay[k] - y0; }
+    float S0, C0;
+    sincos_acc(th0, S0, C0);
+    const float t_end = h_total;
+    float t = 0.0f, X = 0.0f, Y = 0.0f, vx = vx0, vy = vy0;
+    double Xd = 0.0, Yd = 0.0;
+    float k0[4], k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
+
+    // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
+    k0[0] = vx; k0[1] = vy;
+    accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
+    float h_abs;
+    {
+        // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega)
+        float sx = fmaf(fabsf(x0), kRtol, kAtol), sy = fmaf(fabsf(y0), kRtol, kAtol);
+        float sth = fmaf(fabsf(th0), kRtol, kAtol), som = fmaf(fabsf(om), kRtol, kAtol);
+        float svx = fmaf(fabsf(vx), kRtol, kAtol), svy = fmaf(fabsf(vy), kRtol, kAtol);
+        float isx = rcp(sx), isy = rcp(sy), isth = rcp(sth), isom = rcp(som), isvx = rcp(svx), isvy = rcp(svy);
+        float a0 = x0 * isx, a1 = y0 * isy, a2 = th0 * isth, a3 = vx * isvx, a4 = vy * isvy, a5 = om * isom;
+        float d0 = fsqrt((a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5) * (1.0f / 6));
+        // f0 = (vx, vy, omega, ax, ay, 0)
+        float b0 = vx * isx, b1 = vy * isy, b2 = om * isth, b3 = k0[2] * isvx, b4 = k0[3] * isvy;
+        float d1 = fsqrt((b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4) * (1.0f / 6));
+        float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);
+        h0 = fminf(h0, t_end);
+        // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)
+        float ax1, ay1;
+        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, h0, h0 * vx, h0 * vy, ax1, ay1);
+        float e0 = h0 * k0[2] * isx, e1 = h0 * k0[3] * isy, e3 = (ax1 - k0[2]) * isvx, e4 = (ay1 - k0[3]) * isvy;
+        float d2 = fsqrt((e0 * e0 + e1 * e1 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
+        float dm = fmaxf(d1, d2);
+        float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
+                                                   : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
+        h_abs = fminf(fminf(100.0f * h0, h1), t_end);
+    }
+
+    // event functions at (t0, y0), ivp.py:646
+    float g[NC + 2];
+#pragma unroll
+    for (int k = 0; k < NC; k++) g[k] = fsqrt(fmaf(cqx[k], cqx[k], cqy[k] * cqy[k])) - cR[k];
+    const float wxp = half_world - x0, wyp = half_world - y0, wxm = half_world + x0, wym = half_world + y0;
+    if (WALLS) { g[NC] = fminf(wxp, wyp); g[NC + 1] = fminf(wxm, wym); }
+
+    o.done = 0; o.event = -1; o.n_rk = 0;
+    bool rejected = false;
+    for (int attempt = 0; attempt < kMaxRkAttempts; attempt++) {
+        if (!(t < t_end)) break;
+        // RungeKutta._step_impl (rk.py:111-176)
+        h_abs = fmaxf(h_abs, 1e-9f);
+        float t_new = t + h_abs;
+        if (t_new - t_end > 0.0f) t_new = t_end;
+        const float h = t_new - t;
+        h_abs = h;
+        // rk_step (rk.py:14-71); K_s = (vx_s, vy_s, ax_s, ay_s)
+        {
+            float dvx = A21 * k0[2], dvy = A21 * k0[3];
+            k1[0] = fmaf(h, dvx, vx); k1[1] = fmaf(h, dvy, vy);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C2, h, t), fmaf(h, A21 * k0[0], X), fmaf(h, A21 * k0[1], Y),
+                          k1[2], k1[3]);
+        }
+        {
+            float s0 = fmaf(A32, k1[0], A31 * k0[0]), s1 = fmaf(A32, k1[1], A31 * k0[1]);
+            float s2 = fmaf(A32, k1[2], A31 * k0[2]), s3 = fmaf(A32, k1[3], A31 * k0[3]);
+            k2[0] = fmaf(h, s2, vx); k2[1] = fmaf(h, s3, vy);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C3, h, t), fmaf(h, s0, X), fmaf(h, s1, Y), k2[2], k2[3]);
+        }
+        {
+            float s[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[i] = fmaf(A43, k2[i], fmaf(A42, k1[i], A41 * k0[i]));
+            k3[0] = fmaf(h, s[2], vx); k3[1] = fmaf(h, s[3], vy);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C4, h, t), fmaf(h, s[0], X), fmaf(h, s[1], Y), k3[2], k3[3]);
+        }
+        {
+            float s[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[i] = fmaf(A54, k3[i], fmaf(A53, k2[i], fmaf(A52, k1[i], A51 * k0[i])));
+            k4[0] = fmaf(h, s[2], vx); k4[1] = fmaf(h, s[3], vy);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C5, h, t), fmaf(h, s[0], X), fmaf(h, s[1], Y), k4[2], k4[3]);
+        }
+        {
+            float s[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                s[i] = fmaf(A65, k4[i], fmaf(A64, k3[i], fmaf(A63, k2[i], fmaf(A62, k1[i], A61 * k0[i]))));
+            k5[0] = fmaf(h, s[2], vx); k5[1] = fmaf(h, s[3], vy);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, t + h, fmaf(h, s[0], X), fmaf(h, s[1], Y), k5[2], k5[3]);
+        }
+        float inc[4];  // y_new - y = h * sum_j B_j K_j
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            inc[i] = h * fmaf(B6, k5[i], fmaf(B5, k4[i], fmaf(B4, k3[i], fmaf(B3, k2[i], B1 * k0[i]))));
+        const float hh = h * h;
+        const double Xdn = Xd + ((double)h * (double)vx + (double)(hh * fmaf(BETA5, k4[2], fmaf(BETA4, k3[2], fmaf(BETA3, k2[2], BETA1 * k0[2])))));
+        const double Ydn = Yd + ((double)h * (double)vy + (double)(hh * fmaf(BETA5, k4[3], fmaf(BETA4, k3[3], fmaf(BETA3, k2[3], BETA1 * k0[3])))));
+        const float Xn = (float)Xdn, Yn = (float)Ydn, vxn = vx + inc[2], vyn = vy + inc[3];
+        k6[0] = vxn; k6[1] = vyn;
+        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, t + h, Xn, Yn, k6[2], k6[3]);  // f_new (FSAL)
+
+        // error norm over six components; theta and omega contribute exactly zero (sum E = 0, d omega/dt = 0)
+        float err2 = 0.0f;
+        {
+            const float ya[4] = {x0 + X, y0 + Y, vx, vy}, yb[4] = {x0 + Xn, y0 + Yn, vxn, vyn};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float e = fmaf(E7, k6[i] - k0[i],
+                               fmaf(E6, k5[i] - k0[i], fmaf(E5, k4[i] - k0[i], fmaf(E4, k3[i] - k0[i], E3 * (k2[i] - k0[i])))));
+                float scale = fmaf(fmaxf(fabsf(ya[i]), fabsf(yb[i])), kRtol, kAtol);
+                float q = e * h * rcp(scale);
+                err2 = fmaf(q, q, err2);
+            }
+        }
+        const float err = fsqrt(err2 * (1.0f / 6));
+        if (!(err < 1.0f)) {  // rejected (also for NaN): shrink and retry
+            h_abs = h * fmaxf(kMinFactor, kSafety * fexp2(-0.2f * flog2(err)));
+            rejected = true;
+            continue;
+        }
+        float factor = (err == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * fexp2(-0.2f * flog2(err)));
+        if (rejected) factor = fminf(1.0f, factor);
+        rejected = false;
+        h_abs = h * factor;
+        o.n_rk++;
+
+        // events over this accepted step (ivp.py:673-694, find_active_events with direction 0)
+        float gn[NC + 2];
+        unsigned mask = 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            float ex = cqx[k] - Xn, ey = cqy[k] - Yn;
+            gn[k] = fsqrt(fmaf(ex, ex, ey * ey)) - cR[k];
+        }
+        if (WALLS) { gn[NC] = fminf(wxp - Xn, wyp - Yn); gn[NC + 1] = fminf(wxm + Xn, wym + Yn); }
+#pragma unroll
+        for (int k = 0; k < NC + (WALLS ? 2 : 0); k++)
+            if ((g[k] <= 0.0f && gn[k] >= 0.0f) || (g[k] >= 0.0f && gn[k] <= 0.0f)) mask |= 1u << k;
+
+        if (mask) {
+            // dense output over [t, t_new]: y(s) = y_old + h s (K0 + s (Q1 + s (Q2 + s Q3))), s in [0, 1]
+            float q1[4], q2[4], q3[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float d2_ = k2[i] - k0[i], d3_ = k3[i] - k0[i], d4_ = k4[i] - k0[i], d5_ = k5[i] - k0[i], d6_ = k6[i] - k0[i];
+                q1[i] = fmaf(P71, d6_, fmaf(P61, d5_, fmaf(P51, d4_, fmaf(P41, d3_, P31 * d2_))));
+                q2[i] = fmaf(P72, d6_, fmaf(P62, d5_, fmaf(P52, d4_, fmaf(P42, d3_, P32 * d2_))));
+                q3[i] = fmaf(P73, d6_, fmaf(P63, d5_, fmaf(P53, d4_, fmaf(P43, d3_, P33 * d2_))));
+            }
+            auto disp = [&](int i, float s) { return h * s * fmaf(s, fmaf(s, fmaf(s, q3[i], q2[i]), q1[i]), k0[i]); };
+            auto dispd = [&](int i, float s) {  // d disp / ds
+                return h * fmaf(s, fmaf(s, fmaf(4.0f * s, q3[i], 3.0f * q2[i]), 2.0f * q1[i]), k0[i]);
+            };
+            float best = 2.0f;
+            int best_k = -1;
+            float bax = 0.0f, bay = 0.0f;  // absolute centre of the winning circle event
+            double bRd = 0.0;
+            unsigned m = mask;
+            while (m) {  // usually one active event; all are terminal -> the earliest root wins (ivp.py:115-126)
+                int k = __builtin_ctz(m);
+                m &= m - 1;
+                // per-lane event description (selects, no dynamic register indexing)
+                float ecx = 0.0f, ecy = 0.0f, eR = 0.0f, eax = 0.0f, eay = 0.0f, ga = 0.0f, gb = 0.0f;
+                double eRd = 0.0;
+#pragma unroll
+                for (int j = 0; j < NC + (WALLS ? 2 : 0); j++)
+                    if (j == k) {
+                        ga = g[j]; gb = gn[j];
+                        if (j < NC) { ecx = cqx[j]; ecy = cqy[j]; eR = cR[j]; eax = cax[j]; eay = cay[j]; eRd = cRd[j]; }
+                    }
+                const bool circle = k < NC, wmax = (k == NC);
+                auto gfun = [&](float s) {
+                    float dx = X + disp(0, s), dy = Y + disp(1, s);
+                    float ex = ecx - dx, ey = ecy - dy;
+                    float gc = fsqrt(fmaf(ex, ex, ey * ey)) - eR;
+                    float gw = wmax ? fminf(wxp - dx, wyp - dy) : fminf(wxm + dx, wym + dy);
+                    return circle ? gc : gw;
+                };
+                // Illinois (modified regula falsi) on the bracket [0, 1]
+                float a = 0.0f, b = 1.0f;
+                for (int it = 0; it < kRootIters; it++) {
+                    float den = gb - ga;
+                    float c = (den == 0.0f) ? b : b - gb * (b - a) * rcp(den);
+                    c = fminf(fmaxf(c, 0.0f), 1.0f);
+                    float gc = gfun(c);
+                    if (gc * gb < 0.0f) { a = b; ga = gb; } else { ga *= 0.5f; }
+                    b = c; gb = gc;
+                }
+                if (b < best) { best = b; best_k = k; bax = eax; bay = eay; bRd = eRd; }
+            }
+            // One Newton step on the winning event with g evaluated in fp64 from the unrounded inputs: the Goal
+            // reward multiplies the terminal position by up to 1000 (goal.py:147-152), so fp32 noise in g (~1e-7)
+            // would show.  The slope only needs a few digits.
+            {
+                const float s = best;
+                const float dx = X + disp(0, s), dy = Y + disp(1, s), ux = dispd(0, s), uy = dispd(1, s);
+                double gd;
+                float gp;
+                if (best_k < NC) {
+                    const double ex = ((double)bax - (double)x0) - (double)dx, ey = ((double)bay - (double)y0) - (double)dy;
+                    const double r2 = ex * ex + ey * ey, ir = rsqrt_f64(r2);
+                    gd = r2 * ir - bRd;
+                    gp = -((float)ex * ux + (float)ey * uy) * (float)ir;
+                } else {
+                    const double sgn = (best_k == NC) ? 1.0 : -1.0, hw = (double)half_world;
+                    const double gx_ = hw - sgn * ((double)x0 + (double)dx), gy_ = hw - sgn * ((double)y0 + (double)dy);
+                    gd = gx_ < gy_ ? gx_ : gy_;
+                    gp = (float)(-sgn) * (gx_ < gy_ ? ux : uy);
+                }
+                if (fabsf(gp) > 1e-12f) best = fminf(fmaxf(s - (float)gd * rcp(gp), 0.0f), 1.0f);
+            }
+            const float s = best;
+            // leading term h s v in fp64, the O(h^2) remainder in fp32
+            const double hs = (double)h * (double)s;
+            o.dXd = Xd + (hs * (double)vx + (double)(h * s * s * fmaf(s, fmaf(s, q3[0], q2[0]), q1[0])));
+            o.dYd = Yd + (hs * (double)vy + (double)(h * s * s * fmaf(s, fmaf(s, q3[1], q2[1]), q1[1])));
+            o.dX = (float)o.dXd; o.dY = (float)o.dYd;
+            o.vx = vx + disp(2, s); o.vy = vy + disp(3, s);
+            o.t = fmaf(h, s, t);
+            o.done = 1; o.event = best_k;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NC + (WALLS ? 2 : 0); k++) g[k] = gn[k];
+        t = t_new; X = Xn; Y = Yn; Xd = Xdn; Yd = Ydn; vx = vxn; vy = vyn;
+#pragma unroll
+        for (int i = 0; i < 4; i++) k0[i] = k6[i];
+    }
+    o.dXd = Xd; o.dYd = Yd; o.dX = X; o.dY = Y; o.vx = vx; o.vy = vy; o.t = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Observation: spaceship_env.py:113-140.  The reference builds the lidar as
+// unit(atan2(v)) * (|v| - r) * 2 / W, which equals v * (1 - r/|v|) * 2/W without any trigonometry.
+// ------------------------------------------------------------------------------------------------
+SG_FN void lidar(float vx, float vy, float r, float two_over_w, float &ox, float &oy) {
+    float r2 = fmaf(vx, vx, vy * vy);
+    float k = (r2 > 0.0f) ? (1.0f - r * rsq(r2)) * two_over_w : 0.0f;
+    ox = vx * k;
+    oy = vy * k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Goal reward (goal.py:147-158).  The reference amplifies position differences x500 / x1000, so the
+// distances are formed in fp64 from the UNROUNDED end position x0 + dX:
+//   |last - c| - |cur - c| = (|last - c|^2 - |cur - c|^2) / (|last - c| + |cur - c|)
+// with the numerator in fp64 and the denominator from fp32 square roots refined by one Newton step.
+// ------------------------------------------------------------------------------------------------
+SG_FN double dist_drop(double lx, double ly, double cx, double cy, double &cur2) {
+    double l2 = lx * lx + ly * ly;
+    cur2 = cx * cx + cy * cy;
+    double s = l2 * rsqrt_f64(l2 > 0 ? l2 : 1.0) + cur2 * rsqrt_f64(cur2 > 0 ? cur2 : 1.0);  // |last| + |cur|
+    return s > 0 ? (l2 - cur2) / s : 0.0;
+}
+
+template <int N>
+SG_FN float goal_reward(const SgDev &c, float x0, float y0, double dX, double dY, const float (&px)[N],
+                        const float (&py)[N], float gx, float gy, int &hit) {
+    const double lx = x0, ly = y0, cx = lx + dX, cy = ly + dY;
+    double gcur2;
+    double goal_drop = dist_drop((double)gx - lx, (double)gy - ly, (double)gx - cx, (double)gy - cy, gcur2);
+    // _safety_reward_simple2 (goal.py:204-227): planet whose CENTRE is nearest to the new position, first wins ties
+    int closest = 0;
+    float best = 3.0e38f;
+    const float fx = (float)cx, fy = (float)cy;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        float ex = fx - px[j], ey = fy - py[j];
+        float d2 = fmaf(ex, ex, ey * ey);
+        if (d2 < best) { best = d2; closest = j; }
+    }
+    float pcx = px[0], pcy = py[0];
+#pragma unroll
+    for (int j = 1; j < N; j++)
+        if (j == closest) { pcx = px[j]; pcy = py[j]; }
+    double pcur2;
+    double planet_drop = dist_drop(lx - (double)pcx, ly - (double)pcy, cx - (double)pcx, cy - (double)pcy, pcur2);
+    double safety = 0.0;
+    if (pcur2 < c.danger_r2 && planet_drop > 0.0) safety = -planet_drop;  // goal.py:221-225
+    double reward = c.survival + c.goal_scale * goal_drop + c.safety_scale * safety;
+    hit = gcur2 < c.goal_r2;  // goal.py:154
+    if (hit) reward += c.sparse;
+    return (float)reward;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kepler reward (kepler.py:111-156): fp64 on the unrounded end state; orbit (a, ecc, phi) may be per env.
+// reward = C / (Cr |cur_rad - target_rad| + |Vx - vx| + |Vy - vy| + Ca ||action|| + C) has slope -r^2/C,
+// i.e. up to 100 at r ~ 1, which is why fp32 state rounding is kept out of it.
+// ------------------------------------------------------------------------------------------------
+struct Orbit { double a, b, c, ecc, cosphi, sinphi, a_over_b, b_over_a, inv_a; };
+
+SG_FN float kepler_reward(const SgDev &c, const Orbit &ob, float x0, float y0, double dX, double dY, float vx, float vy,
+                          float engine, float thruster) {
+    const double x = (double)x0 + dX, y = (double)y0 + dY;
+    // _rotate(pos, phi) (kepler.py:51-58), then shift by the focal distance (kepler.py:68-73)
+    double wx = ob.cosphi * x + ob.sinphi * y - ob.c, wy = -ob.sinphi * x + ob.cosphi * y;
+    double w2 = wx * wx + wy * wy;
+    double iw = rsqrt_f64(w2);
+    double cur_rad = w2 * iw;                       // _orbit_cur_rad (kepler.py:90-96)
+    double ect = ob.ecc * wx * iw;                  // ecc * cos(theta), theta = atan2(wy, wx)
+    double target_rad = ob.b * rsqrt_f64(1.0 - ect * ect);  // kepler.py:75,109
+    double sc = target_rad * iw;
+    double px_ = wx * sc, py_ = wy * sc;            // projection onto the orbit
+    double tx = -ob.a_over_b * py_, ty = ob.b_over_a * px_;  // kepler.py:77-78 (curl = 1)
+    double rx = px_ + ob.c;
+    double ir = rsqrt_f64(rx * rx + py_ * py_);     // 1 / r
+    double v2 = c.k_gm * (2.0 * ir - ob.inv_a);   // _orbit_vel^2 (kepler.py:60-62)
+    double speed = v2 > 0 ? v2 * rsqrt_f64(v2) : 0.0;
+    double it = rsqrt_f64(tx * tx + ty * ty);
+    double ux = tx * it * speed, uy = ty * it * speed;
+    double Vx = ob.cosphi * ux - ob.sinphi * uy, Vy = ob.sinphi * ux + ob.cosphi * uy;  // _rotate(Vt, -phi)
+    double rad_pen = fabs(cur_rad - target_rad);
+    double vxp = fabs(Vx - (double)vx), vyp = fabs(Vy - (double)vy);
+    // np.linalg.norm(last_action) on the float32 translated action, times act_penalty_C, in float32
+    float act = c.k_Ca * fsqrt(fmaf(engine, engine, thruster * thruster));
+    return (float)(c.k_C / (c.k_Cr * rad_pen + vxp + vyp + (double)act + c.k_C));
+}
+
+SG_FN Orbit make_orbit(double a, double ecc, double cosphi, double sinphi) {
+    Orbit ob;
+    ob.a = a; ob.ecc = ecc; ob.cosphi = cosphi; ob.sinphi = sinphi;
+    double b2 = a * a * (1.0 - ecc * ecc);
+    ob.b = b2 * rsqrt_f64(b2);                      // _b (kepler.py:43-45)
+    double c2 = a * a - b2;
+    ob.c = c2 > 0 ? c2 * rsqrt_f64(c2) : 0.0;       // _c (kepler.py:47-49)
+    ob.a_over_b = a / ob.b; ob.b_over_a = ob.b / a; ob.inv_a = 1.0 / a;
+    return ob;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter =
+// (global env index, episode, block, stream); a reset expands its four words with xoshiro128++.
+// ------------------------------------------------------------------------------------------------
+SG_FN uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+SG_FN void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1;
+        c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+constexpr uint32_t kStreamReset = 0u, kStreamGoal = 1u;
+
+struct Xo128 {
+    uint32_t s0, s1, s2, s3;
+    SG_MFN uint32_t next() {  // xoshiro128++ (Blackman & Vigna)
+        uint32_t r = s0 + s3;
+        r = ((r << 7) | (r >> 25)) + s0;
+        uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+        s2 ^= t;
+        s3 = (s3 << 11) | (s3 >> 21);
+        return r;
+    }
+};
+
+SG_FN float u23(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }       // (0,1), exact
+SG_FN float u16(uint32_t h) { return ((float)(h & 0xffffu) + 0.5f) * (1.0f / 65536.0f); }    // (0,1), exact
+SG_FN uint32_t below16(uint32_t h, uint32_t n) { return ((h & 0xffffu) * n) >> 16; }
+
+// Per-episode tiling layout + the free-tile multiset (hexagonal_tiling.py:42-43,62-72,91).
+// The free list of the reference is an ordered list that can hold duplicates (:101-106); candidates are
+// drawn by POSITION without replacement and ties go to the first DRAWN, so only the multiset matters.
+// It is kept as sixteen 4-bit counters (saturating at 15) indexed by tile number, positions taken in
+// ascending tile order.
+struct Tiling {
+    uint32_t episode, goal_draws;
+    uint32_t ship_tile, goal_tile, case_b, flip;
+    uint64_t free_counts;
+    float col_shift[4];
+};
+
+SG_FN uint32_t free_total(uint64_t f) {
+    uint64_t s = (f & 0x0f0f0f0f0f0f0f0full) + ((f >> 4) & 0x0f0f0f0f0f0f0f0full);
+    return (uint32_t)((s * 0x0101010101010101ull) >> 56);
+}
+// tile at position `pos` of the sorted multiset (pos < total)
+SG_FN uint32_t free_at(uint64_t f, uint32_t pos) {
+    uint32_t tile = 0, acc = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 16; t++) {
+        uint32_t cnt = (uint32_t)(f >> (4 * t)) & 15u;
+        if (pos >= acc && pos < acc + cnt) tile = t;
+        acc += cnt;
+    }
+    return tile;
+}
+SG_FN uint64_t free_add(uint64_t f, uint32_t tile) {
+    uint32_t cnt = (uint32_t)(f >> (4 * tile)) & 15u;
+    return cnt < 15u ? f + (1ull << (4 * tile)) : f;
+}
+SG_FN uint64_t free_remove(uint64_t f, uint32_t tile) { return f - (1ull << (4 * tile)); }
+
+// hexagonal_tiling.py:136-158 _tile_center_pos
+SG_FN void tile_center(const SgDev &c, const Tiling &T, uint32_t tile, float &x, float &y) {
+    uint32_t row = tile / (uint32_t)c.t_cols, col = tile - row * (uint32_t)c.t_cols;
+    float shift = T.col_shift[0];
+#pragma unroll
+    for (uint32_t j = 1; j < 4; j++)
+        if (j == col) shift = T.col_shift[j];
+    float tx = c.t_x0 + (float)col * 1.5f * c.t_a + shift;
+    float y0 = T.case_b ? c.t_y0 - 0.5f * c.t_hex_h : c.t_y0;
+    float ycol = (col & 1u) ? 0.5f * c.t_hex_h : 0.0f;
+    float ty = y0 - (float)row * c.t_hex_h + (T.case_b ? ycol : -ycol);
+    x = T.flip ? ty : tx;
+    y = T.flip ? tx : ty;
+}
+
+// helpers.py:48-53 uniform_disk_distribution inside a tile (hexagonal_tiling.py:130-134); word = angle:hi16 | r:lo16
+SG_FN void disc_in_tile(const SgDev &c, const Tiling &T, uint32_t tile, float noise_radius, uint32_t w, float &x, float &y) {
+    float s, co;
+    sincos_acc(kTwoPi * u16(w >> 16), s, co);
+    float r = noise_radius * fsqrt(u16(w));
+    tile_center(c, T, tile, x, y);
+    x = fmaf(r, co, x);
+    y = fmaf(r, s, y);
+}
+
+// hexagonal_tiling.py:99-128 _reset_goal_tile_nr + :95-97 find_new_goal.  w = [gate, cand0:cand1, cand2:-, disc]
+SG_FN void choose_goal(const SgDev &c, Tiling &T, bool first, const uint32_t (&w)[4], float &gx, float &gy) {
+    if (!first) {  // :101-106 the ship now sits on the tile of the goal it reached
+        T.free_counts = free_add(T.free_counts, T.ship_tile);
+        T.ship_tile = T.goal_tile;
+    }
+    if ((w[0] & 0xffu) < 64u) {  // uniform() < 0.25, :108-110
+        T.goal_tile = T.ship_tile;
+    } else {
+        const uint32_t n = free_total(T.free_counts), n_cand = n < 3u ? n : 3u;
+        const uint32_t cols = (uint32_t)c.t_cols, sr = T.ship_tile / cols, sc = T.ship_tile - sr * cols;
+        const uint32_t draws[3] = {w[1] >> 16, w[1], w[2] >> 16};
+        // choice(n, size=n_cand, replace=False) as a partial Fisher-Yates over positions 0..n-1 (slot i swaps with
+        // slot j_i >= i).  With at most three draws the touched slots are tracked by value, not in an array:
+        //   after swap 0: slot 0 holds j0 and slot j0 holds 0; after swap 1: slot j1 holds what slot 1 held.
+        uint32_t chosen[3] = {0u, 0u, 0u};
+        const uint32_t j0 = below16(draws[0], n);
+        chosen[0] = j0;
+        const uint32_t v1_old = (j0 == 1u) ? 0u : 1u;  // content of slot 1 before swap 1
+        uint32_t j1 = 0xffffffffu;
+        if (n_cand > 1) {
+            j1 = 1u + below16(draws[1], n - 1u);
+            chosen[1] = (j1 == j0) ? 0u : j1;
+        }
+        if (n_cand > 2) {
+            const uint32_t j2 = 2u + below16(draws[2], n - 2u);
+            chosen[2] = (j2 == j1) ? v1_old : (j2 == j0) ? 0u : j2;
+        }
+        uint32_t best_tile = 0;
+        int best_dist = -1;
+        for (uint32_t i = 0; i < n_cand; i++) {
+            uint32_t tile = free_at(T.free_counts, chosen[i]);
+            uint32_t r = tile / cols, cc = tile - r * cols;
+            int dist = abs((int)r - (int)sr) + abs((int)cc - (int)sc);  // :119-121
+            if (dist > best_dist) { best_dist = dist; best_tile = tile; }  // first max, :122-124
+        }
+        T.goal_tile = best_tile;
+        T.free_counts = free_remove(T.free_counts, best_tile);  // pop, :126
+    }
+    disc_in_tile(c, T, T.goal_tile, c.noise_goal, w[3], gx, gy);
+}
+
+SG_FN void box_muller(uint32_t w1, uint32_t w2, float &z0, float &z1) {
+    float r = fsqrt(-2.0f * 0.6931471805599453f * flog2(u23(w1)));
+    float s, co;
+    sincos_acc(kTwoPi * u23(w2), s, co);
+    z0 = r * co;
+    z1 = r * s;
+}
+
+struct ShipInit { float x, y, th, vx, vy, om; };
+
+// GoalEnv._reset (goal.py:133-145) + HexagonalTiling.reset (hexagonal_tiling.py:53-93)
+template <int N>
+SG_FN void goal_reset(const SgDev &c, uint32_t env_global, Tiling &T, ShipInit &s, float (&px)[N], float (&py)[N],
+                      float &gx, float &gy) {
+    uint32_t w[4];
+    philox4x32_10(c.seed_lo, c.seed_hi, env_global, T.episode, 0u, kStreamReset, w);
+    Xo128 g = {w[0] | 1u, w[1], w[2], w[3]};
+    T.goal_draws = 0;
+    const uint32_t flags = g.next();
+    T.case_b = flags & 1u; T.flip = (flags >> 1) & 1u;  // hexagonal_tiling.py:69
+    {
+        const uint32_t c01 = g.next(), c23 = g.next();
+        const float u[4] = {u16(c01 >> 16), u16(c01), u16(c23 >> 16), u16(c23)};
+        float cum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {  // :70 cumsum over the first t_cols columns
+            if (j < c.t_cols) cum += u[j];
+            T.col_shift[j] = (j < c.t_cols) ? cum : 0.0f;
+        }
+        const float k = c.t_free_x * rcp(cum);  // :71-72
+#pragma unroll
+        for (int j = 0; j < 4; j++) T.col_shift[j] *= k;
+    }
+    uint32_t tiles[N + 1];
+    {
+        const uint32_t t01 = g.next(), t23 = g.next(), t45 = g.next();
+        const uint32_t draws[6] = {t01 >> 16, t01, t23 >> 16, t23, t45 >> 16, t45};
+        // choice(n_tiles, size=N+1, replace=False) (:89): Fisher-Yates on a 16-nibble permutation word
+        uint64_t perm = 0xfedcba9876543210ull;
+        const uint32_t nt = (uint32_t)c.t_tiles;
+#pragma unroll
+        for (uint32_t i = 0; i <= (uint32_t)N; i++) {
+            uint32_t j = i + below16(draws[i], nt - i);
+            uint64_t vi = (perm >> (4 * i)) & 15ull, vj = (perm >> (4 * j)) & 15ull;
+            perm = (perm & ~((15ull << (4 * i)) | (15ull << (4 * j)))) | (vj << (4 * i)) | (vi << (4 * j));
+            tiles[i] = (uint32_t)vj;
+        }
+        if (N == 2 && ((flags >> 8) & 0xffu) < 64u) {  // :75-87 the four diagonal layouts, w.p. 0.25
+            const uint32_t d = (flags >> 16) & 3u;
+            tiles[0] = (d == 0) ? 1u : (d == 1) ? 2u : (d == 2) ? 0u : 3u;
+            tiles[1] = (d < 2) ? 0u : 1u;
+            tiles[2] = (d < 2) ? 3u : 2u;
+        }
+        uint64_t used = 0;
+#pragma unroll
+        for (int i = 0; i <= N; i++) used |= 1ull << (4 * tiles[i]);
+        const uint64_t all = (nt >= 16u) ? 0x1111111111111111ull : (0x1111111111111111ull & ((1ull << (4 * nt)) - 1ull));
+        T.free_counts = all & ~used;  // :91
+    }
+    T.ship_tile = tiles[0];  // :90
+    disc_in_tile(c, T, tiles[0], c.noise_ship, g.next(), s.x, s.y);  // :92-93
+#pragma unroll
+    for (int j = 0; j < N; j++) disc_in_tile(c, T, tiles[j + 1], c.noise_planet, g.next(), px[j], py[j]);
+    {
+        const uint32_t gw[4] = {flags >> 24, g.next(), g.next(), g.next()};
+        T.goal_tile = 0xffu;
+        choose_goal(c, T, true, gw, gx, gy);  // goal.py:138
+    }
+    s.th = kTwoPi * u23(g.next());  // goal.py:140
+    float z0, z1, z2, z3;
+    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z0, z1); }
+    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z2, z3); }
+    s.vx = z0 * c.vel_std; s.vy = z1 * c.vel_std;                               // goal.py:141
+    s.om = fminf(fmaxf(z2 * c.omega_std, -c.omega_max), c.omega_max);           // goal.py:142-144
+}
+
+// GoalEnv._resample_goal on a hit (goal.py:154-157 -> hexagonal_tiling.py:95-134)
+SG_FN void goal_resample(const SgDev &c, uint32_t env_global, Tiling &T, float &gx, float &gy) {
+    uint32_t w[4];
+    T.goal_draws += 1;
+    philox4x32_10(c.seed_lo, c.seed_hi, env_global, T.episode, T.goal_draws, kStreamGoal, w);
+    choose_goal(c, T, false, w, gx, gy);
+}
+
+// KeplerEnv._reset (kepler.py:233-267)
+SG_FN void kepler_reset(const SgDev &c, uint32_t env_global, uint32_t episode, ShipInit &s, float &phi, float &ecc) {
+    uint32_t w[4];
+    philox4x32_10(c.seed_lo, c.seed_hi, env_global, episode, 0u, kStreamReset, w);
+    Xo128 g = {w[0] | 1u, w[1], w[2], w[3]};
+    float sa, ca;
+    sincos_acc(kTwoPi * u23(g.next()), sa, ca);
+    float dist = fmaf(c.kep_rmax - c.kep_rmin, u23(g.next()), c.kep_rmin);
+    s.x = ca * dist; s.y = sa * dist;
+    s.th = kTwoPi * u23(g.next());
+    const uint32_t we = g.next(), wa = g.next();
+    if (c.randomize_orbit) { ecc = u23(we) * 0.7f; phi = u23(wa) * kTwoPi; }    // kepler.py:257-259
+    float z0, z1, z2, z3;
+    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z0, z1); }
+    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z2, z3); }
+    s.vx = z0 * c.vel_std; s.vy = z1 * c.vel_std;
+    s.om = fminf(fmaxf(z2 * c.omega_std, -c.omega_max), c.omega_max);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One env in registers, and SpaceshipEnv.step (spaceship_env.py:68-78) on it.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct GoalEnv {
+    float x, y, th, vx, vy, om;
+    float gx, gy;
+    float px[N], py[N];
+};
+struct KeplerEnv {
+    float x, y, th, vx, vy, om;
+    float phi, ecc;  // per-env reference orbit (KeplerRandomOrbits); ignored for the fixed-orbit ids
+};
+
+// ContinuousSpaceshipEnv._translate_raw_action (spaceship_env.py:210-214), float32 like the reference.
+// The reference asserts the action is inside [-1, 1]^2 (spaceship_env.py:71); the kernel clamps instead of
+// trapping (the Python wrapper can validate on the host).  NaN actions clamp to -1.
+SG_FN void translate_action(float &a0, float &a1, float max_engine_force, float &engine, float &F, float &om) {
+    a0 = fminf(fmaxf(a0, -1.0f), 1.0f);
+    a1 = fminf(fmaxf(a1, -1.0f), 1.0f);
+    engine = (a0 + 1.0f) * 0.5f;
+    F = engine * max_engine_force;  // dynamic_model.py:171 (float32 product)
+    om = a1 * 5.0f;                 // dynamic_model.py:140
+}
+
+template <int N>
+SG_FN void goal_observe(const SgDev &c, const GoalEnv<N> &e, float (&obs)[7 + 2 * N + 2]) {
+    float s, co;
+    sincos_acc(e.th, s, co);
+    obs[0] = e.x; obs[1] = e.y; obs[2] = co; obs[3] = s; obs[4] = e.vx; obs[5] = e.vy; obs[6] = e.om;
+#pragma unroll
+    for (int j = 0; j < N; j++) lidar(e.px[j] - e.x, e.py[j] - e.y, c.planet_r, c.two_over_world, obs[7 + 2 * j], obs[8 + 2 * j]);
+    obs[7 + 2 * N] = (e.gx - e.x) * c.two_over_world;  // goal lidar, radius 0 (spaceship_env.py:129)
+    obs[8 + 2 * N] = (e.gy - e.y) * c.two_over_world;
+}
+
+SG_FN void kepler_observe(const SgDev &c, const KeplerEnv &e, float (&obs)[10]) {
+    float s, co;
+    sincos_acc(e.th, s, co);
+    obs[0] = e.x; obs[1] = e.y; obs[2] = co; obs[3] = s; obs[4] = e.vx; obs[5] = e.vy; obs[6] = e.om;
+    obs[7] = c.randomize_orbit ? e.phi : (float)c.k_phi;  // kepler.py:172-187
+    obs[8] = c.randomize_orbit ? e.ecc : (float)c.k_ecc;
+    obs[9] = (float)c.k_a;
+}
+
+// Goal: integrate -> observation (old goal) -> reward; the caller resamples the goal on a hit (goal.py:154-157)
+template <int N>
+SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, float (&obs)[7 + 2 * N + 2], float &reward,
+                         int &done, int &hit, StepResult &r) {
+    float engine, F, om;
+    translate_action(a0, a1, c.max_engine_force, engine, F, om);
+    float cR[N];
+    double cRd[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { cR[j] = c.planet_r; cRd[j] = c.planet_r_d; }
+    make_step<N, N, true>(c.h, c.half_world, c.gm, F, om, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd, r);
+    reward = goal_reward<N>(c, e.x, e.y, r.dXd, r.dYd, e.px, e.py, e.gx, e.gy, hit);
+    e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = om;
+    e.th = wrap_two_pi(fmaf(om, r.t, e.th));
+    done = r.done;
+    goal_observe<N>(c, e, obs);
+}
+
+SG_FN Orbit fixed_orbit(const SgDev &c) {
+    Orbit ob;
+    ob.a = c.k_a; ob.b = c.k_b; ob.c = c.k_c; ob.ecc = c.k_ecc; ob.cosphi = c.k_cos; ob.sinphi = c.k_sin;
+    ob.a_over_b = c.k_a / c.k_b; ob.b_over_a = c.k_b / c.k_a; ob.inv_a = 1.0 / c.k_a;
+    return ob;
+}
+
+SG_FN void kepler_env_step(const SgDev &c, const Orbit &ob, KeplerEnv &e, float a0, float a1, float (&obs)[10],
+                           float &reward, int &done, StepResult &r) {
+    float engine, F, om;
+    translate_action(a0, a1, c.max_engine_force, engine, F, om);
+    // planet (R = 0.2, gravitating) and the zero-mass border circle (R = 3, crossed from inside), both at the origin
+    // (kepler.py:204-206).  The world_max/min walls at +-3 enclose the border circle and can never fire first.
+    const float cax[2] = {0.0f, 0.0f}, cay[2] = {0.0f, 0.0f}, cR[2] = {c.planet_r, c.border_r};
+    const double cRd[2] = {c.planet_r_d, (double)c.border_r};
+    make_step<2, 1, false>(c.h, c.half_world, c.gm, F, om, e.x, e.y, e.th, e.vx, e.vy, cax, cay, cR, cRd, r);
+    reward = kepler_reward(c, ob, e.x, e.y, r.dXd, r.dYd, r.vx, r.vy, engine, a1);
+    e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = om;
+    e.th = wrap_two_pi(fmaf(om, r.t, e.th));
+    done = r.done;
+    kepler_observe(c, e, obs);
+}
+
+}  // namespace sg
+#endif

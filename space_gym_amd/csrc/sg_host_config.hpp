@@ -1,0 +1,102 @@
+/*
+ * sg_host_config.hpp -- fills the SgDev parameter block for a registered env id (host side).
+ * Constants restate gym_space/__init__.py:26-146 (ids, kwargs, max_episode_steps), goal.py:10-72,
+ * kepler.py:17-18,189-231, hexagonal_tiling.py:8-48,161-174 and helpers.py:19 of the reference.
+ */
+#ifndef SG_HOST_CONFIG_HPP
+#define SG_HOST_CONFIG_HPP
+
+#include <cmath>
+#include <cstring>
+
+#include "sg_config.h"
+
+namespace sg {
+
+// hexagonal_tiling.py:161-174: smallest rows x cols hexagon grid with >= min_tiles tiles that fits the world
+inline void tiling_grid(int min_tiles, double world, int &rows, int &cols, double &a) {
+    const double s3 = std::sqrt(3.0);
+    int r = (int)std::ceil(std::sqrt(72.0 * s3 * min_tiles - 6.0 * s3 + 12.0) / 12.0 - 0.25 + s3 / 12.0);
+    int c;
+    for (;; ++r) {
+        c = (int)std::floor(2.0 * s3 * r / 3.0 - 1.0 / 3.0 + s3 / 3.0);
+        if (r * c >= min_tiles) break;
+    }
+    rows = r; cols = c;
+    a = 2.0 * s3 * world / (3.0 * (2.0 * r + 1.0));
+}
+
+inline void fill_common(SgDev &d) {
+    std::memset(&d, 0, sizeof(d));
+    d.max_episode_steps = 500;  // gym_space/__init__.py:29,45,61,82
+    d.auto_reset = 1;
+    d.h = 0.07f;                // goal.py:66; gym_space/__init__.py:76
+    d.max_engine_force = 0.4f;  // gym_space/__init__.py:38; kepler.py:199
+    d.omega_max = (float)(0.7 * 6.0);  // goal.py:142, kepler.py:263 with max_abs_vel_angle = 6
+}
+
+inline void fill_goal(SgDev &d, int n_planets) {
+    fill_common(d);
+    const double G = 6.6743e-11, world = 3.0, s3 = std::sqrt(3.0);
+    d.family = SG_FAMILY_GOAL;
+    d.n_planets = n_planets;
+    d.half_world = (float)(world / 2);
+    d.two_over_world = (float)(2.0 / world);
+    d.gm = (float)(G * 1.0 * (1e9 / n_planets));  // goal.py:14,43,46
+    int n_objects = n_planets + 2, rows, cols;
+    int min_tiles = (n_planets == 2) ? n_objects : (int)std::ceil(n_objects / 0.6);  // hexagonal_tiling.py:8,26-29
+    double a;
+    tiling_grid(min_tiles, world, rows, cols, a);
+    const double hex_h = a * s3, planet_r = 0.75 * hex_h / 2, small_r = planet_r / 2;  // :37,45-48
+    d.planet_r = (float)planet_r; d.planet_r_d = planet_r;
+    d.goal_r2 = small_r * small_r;
+    d.danger_r2 = (planet_r + 0.25) * (planet_r + 0.25);  // goal.py:24
+    d.survival = 0.2; d.goal_scale = 5.0 * 100.0; d.safety_scale = 10.0 * 100.0; d.sparse = 5.0;  // __init__.py:34-37, goal.py:16
+    d.t_rows = rows; d.t_cols = cols; d.t_tiles = rows * cols;
+    d.t_a = (float)a; d.t_hex_h = (float)hex_h;
+    d.t_x0 = (float)(-world / 2 + a);          // hexagonal_tiling.py:145 (hex_width / 2 = a)
+    d.t_y0 = (float)(world / 2 - hex_h / 2);   // :146
+    d.t_free_x = (float)(world - (3 * a * (cols - 1) / 2 + 2 * a));  // :39,71
+    d.noise_ship = (float)(hex_h / 2 - small_r);
+    d.noise_planet = (float)(hex_h / 2 - planet_r);
+    d.noise_goal = (float)(hex_h / 2 - small_r);
+    d.vel_std = 0.07f;                        // goal.py:141
+    d.omega_std = (float)(0.7 * 6.0 / 3.0);   // goal.py:142-143
+}
+
+inline void fill_kepler(SgDev &d, double a, double ecc, double phi, int randomize) {
+    fill_common(d);
+    const double G = 6.6743e-11;
+    d.family = SG_FAMILY_KEPLER;
+    d.n_planets = 1;
+    d.half_world = 3.0f; d.two_over_world = (float)(2.0 / 6.0);  // kepler.py:216
+    d.gm = (float)(G * 1.0 * 6e8);  // kepler.py:204
+    d.planet_r = 0.2f; d.planet_r_d = 0.2; d.border_r = 3.0f;  // kepler.py:17-18
+    d.k_a = a; d.k_ecc = ecc; d.k_phi = phi;
+    d.k_b = std::sqrt(a * a * (1 - ecc * ecc));
+    d.k_c = std::sqrt(a * a - d.k_b * d.k_b);
+    d.k_cos = std::cos(phi); d.k_sin = std::sin(phi);
+    d.k_gm = G * 6e8;
+    d.k_C = 0.01; d.k_Cr = 2.0; d.k_Ca = 0.5f;  // gym_space/__init__.py:86-88
+    d.randomize_orbit = randomize;
+    d.vel_std = 0.05f;                        // kepler.py:261
+    d.omega_std = (float)(0.7 * 6.0 / 5.0);   // kepler.py:263-264
+    d.kep_rmin = 0.2f + 0.5f; d.kep_rmax = 3.0f - 0.5f;  // kepler.py:235-237
+}
+
+// returns 0 on success, -1 for an id the engine does not serve
+inline int fill_config(const char *id, SgDev &d) {
+    if (!std::strcmp(id, "GoalContinuous2P-v0")) { fill_goal(d, 2); return 0; }
+    if (!std::strcmp(id, "GoalContinuous3P-v0")) { fill_goal(d, 3); return 0; }
+    if (!std::strcmp(id, "GoalContinuous4P-v0")) { fill_goal(d, 4); return 0; }
+    if (!std::strcmp(id, "KeplerCircleOrbit-v0")) { fill_kepler(d, 1.2, 0.0, 0.0, 0); return 0; }
+    if (!std::strcmp(id, "KeplerEllipseEasy-v0")) { fill_kepler(d, 1.2, 0.5, 0.8, 0); return 0; }
+    if (!std::strcmp(id, "KeplerEllipseHard-v0")) { fill_kepler(d, 1.2, 0.725, 3.925, 0); return 0; }
+    if (!std::strcmp(id, "KeplerRandomOrbits-v0")) { fill_kepler(d, 1.2, 0.5, 3.75, 1); return 0; }  // kepler.py:193-195
+    return -1;
+}
+
+inline int obs_dim(const SgDev &d) { return d.family == SG_FAMILY_GOAL ? 7 + 2 * d.n_planets + 2 : 10; }
+
+}  // namespace sg
+#endif

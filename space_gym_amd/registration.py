@@ -1,0 +1,62 @@
+"""Environment ids served by the engine, with the kwargs the reference registers them with
+(gym_space/__init__.py:26-146).  The native library holds the same constants (csrc/sg_host_config.hpp);
+this table is what the Python surface exposes (spec lookup, spaces, optional gym registration)."""
+import numpy as np
+
+from .spaces import Box
+
+_GOAL_KW = dict(ship_steering=1, ship_moi=0.01, survival_reward_scale=0.2, goal_vel_reward_scale=5.0,
+                safety_reward_scale=10.0, goal_sparse_reward=5.0, max_engine_force=0.4)
+_KEPLER_KW = dict(ship_steering=1, ship_moi=0.01, rad_penalty_C=2, numerator_C=0.01, act_penalty_C=0.5, step_size=0.07)
+
+ENV_SPECS = {
+    "GoalContinuous2P-v0": dict(family="goal", n_planets=2, max_episode_steps=500, kwargs=dict(n_planets=2, **_GOAL_KW)),
+    "GoalContinuous3P-v0": dict(family="goal", n_planets=3, max_episode_steps=500, kwargs=dict(n_planets=3, **_GOAL_KW)),
+    "GoalContinuous4P-v0": dict(family="goal", n_planets=4, max_episode_steps=500, kwargs=dict(n_planets=4, **_GOAL_KW)),
+    "KeplerCircleOrbit-v0": dict(family="kepler", n_planets=0, max_episode_steps=500,
+                                 kwargs=dict(randomize=False, ref_orbit_a=1.2, ref_orbit_eccentricity=0, ref_orbit_angle=0, **_KEPLER_KW)),
+    "KeplerEllipseEasy-v0": dict(family="kepler", n_planets=0, max_episode_steps=500,
+                                 kwargs=dict(randomize=False, ref_orbit_a=1.2, ref_orbit_eccentricity=0.5, ref_orbit_angle=0.8, **_KEPLER_KW)),
+    "KeplerEllipseHard-v0": dict(family="kepler", n_planets=0, max_episode_steps=500,
+                                 kwargs=dict(randomize=False, ref_orbit_a=1.2, ref_orbit_eccentricity=0.725, ref_orbit_angle=3.925, **_KEPLER_KW)),
+    "KeplerRandomOrbits-v0": dict(family="kepler", n_planets=0, max_episode_steps=500, kwargs=dict(randomize=True, **_KEPLER_KW)),
+}
+
+
+def obs_dim(env_id):
+    s = ENV_SPECS[env_id]
+    return 7 + 2 * s["n_planets"] + 2 if s["family"] == "goal" else 10
+
+
+def single_observation_space(env_id):
+    s = ENV_SPECS[env_id]
+    if s["family"] == "goal":  # spaceship_env.py:102-111
+        high = [1.0, 1.0, 1.0, 1.0, np.inf, np.inf, 1.0] + (2 * s["n_planets"] + 2) * [2 * np.sqrt(2)]
+    else:  # kepler.py:158-170 (low = -high including the three orbit slots)
+        high = [1.0, 1.0, 1.0, 1.0, np.inf, np.inf, 1.0, 2 * np.pi, 0.7, 2]
+    high = np.array(high, dtype=np.float32)
+    return Box(-high, high)
+
+
+def single_action_space(env_id):
+    ones = np.ones(2, dtype=np.float32)  # spaceship_env.py:206-208
+    return Box(-ones, ones)
+
+
+def register_with_gym():
+    """Register vector entry points with gym / gymnasium when one of them is importable (neither is required)."""
+    registered = []
+    for modname in ("gymnasium", "gym"):
+        try:
+            mod = __import__(modname)
+        except ImportError:
+            continue
+        for env_id, spec in ENV_SPECS.items():
+            new_id = env_id.replace("-v0", "Vec-v0")
+            try:
+                mod.register(id=new_id, entry_point="space_gym_amd.vector_env:make_vec", kwargs=dict(env_id=env_id),
+                             max_episode_steps=None)
+                registered.append((modname, new_id))
+            except Exception:
+                pass
+    return registered

@@ -1,0 +1,206 @@
+"""gym.vector.VectorEnv-shaped front end of the HIP engine.
+
+Mirrors the reference's env surface for the step path -- `reset() -> obs`, `step(a) -> (obs, reward, done, info)`
+(old-gym 4-tuple, gym_space/envs/spaceship_env.py:59-78), `seed(s)` (:92-94), observation/action spaces
+(:102-111,206-208; kepler.py:158-170) -- batched over `num_envs` instances, with what gym.wrappers.TimeLimit
+(max_episode_steps=500, gym_space/__init__.py:29) and a VectorEnv add: per-env step counters, truncation and
+auto-reset, all inside the step kernel.
+
+Two I/O modes:
+  * NumPy (`reset`, `step`): host arrays in/out through sg_step (H2D + kernel + D2H per call);
+  * torch (`reset_torch`, `step_torch`, `rollout_torch`): device tensors in/out through sg_step_device on torch's
+    current stream, zero-copy -- the high-throughput path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from .registration import ENV_SPECS, obs_dim, single_action_space, single_observation_space
+from .spaces import batch_box
+
+
+class StepInfo(dict):
+    """Batched info: {"TimeLimit.truncated": bool[B], "terminal_observation": float32[B, D] (rows of finished envs)}.
+    A per-env list of dicts (old gym VectorEnv) would cost more than the step itself at B = 65536."""
+
+
+class SpaceGymVectorEnv:
+    metadata = {"render.modes": []}
+
+    def __init__(self, env_id, num_envs, device=0, seed=0, env_index_base=0, max_episode_steps=None, auto_reset=True,
+                 validate_actions=False, terminal_observation=True):
+        if env_id not in ENV_SPECS:
+            raise ValueError(f"unknown env id {env_id!r}; served ids: {sorted(ENV_SPECS)}")
+        self._lib = _native.load()
+        self.env_id, self.num_envs, self.device = env_id, int(num_envs), int(device)
+        self.spec = ENV_SPECS[env_id]
+        self.obs_dim = obs_dim(env_id)
+        self.n_planets = self.spec["n_planets"]
+        self.single_observation_space = single_observation_space(env_id)
+        self.single_action_space = single_action_space(env_id)
+        self.observation_space = batch_box(self.single_observation_space, self.num_envs)
+        self.action_space = batch_box(self.single_action_space, self.num_envs)
+        self.validate_actions = validate_actions
+        self.want_terminal_obs = terminal_observation
+        cfg = _native.SgConfig(env_id=env_id.encode(), num_envs=self.num_envs, seed=int(seed),
+                               env_index_base=int(env_index_base), max_episode_steps=int(max_episode_steps or 0),
+                               auto_reset=int(bool(auto_reset)))
+        h = C.c_void_p()
+        rc = self._lib.sg_create(C.byref(cfg), self.device, C.byref(h))
+        _native.check(self._lib, None, rc, "sg_create")
+        self._h = h
+        assert self._lib.sg_obs_dim(h) == self.obs_dim
+        B, D = self.num_envs, self.obs_dim
+        self._obs = np.empty((B, D), np.float32)
+        self._rew = np.empty(B, np.float32)
+        self._done = np.empty(B, np.uint8)
+        self._trunc = np.empty(B, np.uint8)
+        self._tobs = np.full((B, D), np.nan, np.float32) if terminal_observation else None
+        self._pending = None
+        self._torch_bufs = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        _native.check(self._lib, self._h, rc, what)
+
+    def seed(self, seed=None):
+        """SpaceshipEnv.seed (spaceship_env.py:92-94): returns [seed]; applies from the next reset()."""
+        seed = int(np.random.SeedSequence().entropy % (1 << 63)) if seed is None else int(seed)
+        self._ck(self._lib.sg_seed(self._h, seed), "sg_seed")
+        return [seed]
+
+    def set_auto_reset(self, on):
+        self._ck(self._lib.sg_set_auto_reset(self._h, int(bool(on))), "sg_set_auto_reset")
+
+    # ------------------------------------------------------------------ NumPy path
+    @staticmethod
+    def _ptr(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+    def reset(self):
+        self._ck(self._lib.sg_reset(self._h, self._ptr(self._obs)), "sg_reset")
+        return self._obs.copy()
+
+    def _check_actions(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.float32)  # raw_action.astype(np.float32), spaceship_env.py:69-70
+        if actions.shape != (self.num_envs, 2):
+            raise ValueError(f"actions must have shape ({self.num_envs}, 2), got {actions.shape}")
+        if self.validate_actions:  # assert self.action_space.contains(raw_action), spaceship_env.py:71
+            assert np.all(actions >= -1.0) and np.all(actions <= 1.0), actions
+        return actions
+
+    def step_async(self, actions):
+        self._pending = self._check_actions(actions)
+
+    def step_wait(self):
+        a, self._pending = self._pending, None
+        if a is None:
+            raise RuntimeError("step_wait() without step_async()")
+        rc = self._lib.sg_step(self._h, self._ptr(a), self._ptr(self._obs), self._ptr(self._rew), self._ptr(self._done),
+                               self._ptr(self._trunc), self._ptr(self._tobs))
+        self._ck(rc, "sg_step")
+        info = StepInfo({"TimeLimit.truncated": self._trunc.astype(bool)})
+        if self._tobs is not None:
+            info["terminal_observation"] = self._tobs.copy()
+        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), info
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    # ------------------------------------------------------------------ state access (golden-vector injection, checkpoints)
+    def get_state(self):
+        B, N = self.num_envs, self.n_planets
+        ship = np.empty((B, 6), np.float32)
+        planets = np.empty((B, N, 2), np.float32) if N else None
+        goal = np.empty((B, 2), np.float32)
+        elapsed = np.empty(B, np.int32)
+        self._ck(self._lib.sg_get_state(self._h, self._ptr(ship), self._ptr(planets), self._ptr(goal), self._ptr(elapsed)),
+                 "sg_get_state")
+        return dict(ship=ship, planets=planets, goal=goal, elapsed=elapsed)
+
+    def set_state(self, ship=None, planets=None, goal=None, elapsed=None):
+        B, N = self.num_envs, self.n_planets
+
+        def prep(a, shape, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.shape != shape:
+                raise ValueError(f"expected shape {shape}, got {a.shape}")
+            return a
+        ship, goal = prep(ship, (B, 6), np.float32), prep(goal, (B, 2), np.float32)
+        planets, elapsed = prep(planets, (B, N, 2), np.float32), prep(elapsed, (B,), np.int32)
+        self._ck(self._lib.sg_set_state(self._h, self._ptr(ship), self._ptr(planets), self._ptr(goal), self._ptr(elapsed)),
+                 "sg_set_state")
+
+    # ------------------------------------------------------------------ torch path (device tensors, current stream)
+    def _torch(self):
+        import torch
+        if self._torch_bufs is None:
+            dev = torch.device("cuda", self.device)
+            B, D = self.num_envs, self.obs_dim
+            self._torch_bufs = dict(
+                obs=torch.empty((B, D), dtype=torch.float32, device=dev), reward=torch.empty(B, dtype=torch.float32, device=dev),
+                done=torch.empty(B, dtype=torch.uint8, device=dev), trunc=torch.empty(B, dtype=torch.uint8, device=dev))
+        return torch, self._torch_bufs
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset_torch(self, out=None):
+        torch, bufs = self._torch()
+        obs = bufs["obs"] if out is None else out
+        self._ck(self._lib.sg_reset_device(self._h, C.c_void_p(obs.data_ptr()), self._stream()), "sg_reset_device")
+        return obs
+
+    def step_torch(self, actions, out=None, terminal_obs=None):
+        """actions: float32 CUDA tensor [B, 2].  Returns (obs, reward, done, truncated) device tensors, which are reused
+        by the next call unless `out` (a dict with the same keys) is given."""
+        torch, bufs = self._torch()
+        o = bufs if out is None else out
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous() and tuple(actions.shape) == (self.num_envs, 2)
+        rc = self._lib.sg_step_device(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(o["obs"].data_ptr()),
+                                      C.c_void_p(o["reward"].data_ptr()), C.c_void_p(o["done"].data_ptr()),
+                                      C.c_void_p(o["trunc"].data_ptr()),
+                                      C.c_void_p(terminal_obs.data_ptr()) if terminal_obs is not None else None, self._stream())
+        self._ck(rc, "sg_step_device")
+        return o["obs"], o["reward"], o["done"], o["trunc"]
+
+    def rollout_torch(self, actions, obs, reward, done, trunc):
+        """actions [K, B, 2] -> obs [K, B, D], reward/done/trunc [K, B]: K steps enqueued back to back."""
+        K = actions.shape[0]
+        rc = self._lib.sg_rollout_device(self._h, int(K), C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
+                                         C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),
+                                         C.c_void_p(trunc.data_ptr()), self._stream())
+        self._ck(rc, "sg_rollout_device")
+        return obs, reward, done, trunc
+
+
+    # ------------------------------------------------------------------ measurement aid
+    def set_profiling(self, on):
+        self._ck(self._lib.sg_set_profiling(self._h, int(bool(on))), "sg_set_profiling")
+
+    def get_profile(self):
+        """(launches, total_ms, min_ms, max_ms) of the step-kernel launches since the last call; synchronise first."""
+        n, tot, mn, mx = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        self._ck(self._lib.sg_get_profile(self._h, C.byref(n), C.byref(tot), C.byref(mn), C.byref(mx)), "sg_get_profile")
+        return n.value, tot.value, mn.value, mx.value
+
+
+def make_vec(env_id, num_envs=1, **kwargs):
+    """Batched counterpart of gym.make(env_id) for the ids in gym_space/__init__.py."""
+    return SpaceGymVectorEnv(env_id, num_envs, **kwargs)

@@ -1,0 +1,251 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI (include/spacegym.h via ctypes), against
+(1) the golden vectors captured from the reference and (2) the CPU oracle on the same seeded inputs.
+
+Stated tolerances (fp32 engine vs fp64 reference):
+    state, observation   1e-5 absolute          (theta compared modulo 2 pi)
+    reward               1e-5 * max(1, |r|)     (the Goal reward multiplies position differences by 500..1000)
+    done, goal-hit, event decisions: equal, except inputs within fp32 rounding of a boundary (none in the fixtures)
+"""
+import numpy as np
+import pytest
+
+from conftest import FAMILIES, has_gpu
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_STATE = 1e-5
+TOL_OBS = 1e-5
+TOL_REWARD_REL = 1e-5
+
+
+def circ_diff(a, b):
+    d = np.abs(a - b) % (2 * np.pi)
+    return np.minimum(d, 2 * np.pi - d)
+
+
+def make(env_id, n, **kw):
+    import space_gym_amd as sg
+    return sg.make_vec(env_id, n, device=0, **kw)
+
+
+def check_against(out_obs, out_rew, out_done, s1, ref_state1, ref_obs, ref_rew, ref_done, allow_mismatch=0):
+    same = out_done == ref_done.astype(bool)
+    assert (~same).sum() <= allow_mismatch, f"{(~same).sum()} done mismatches"
+    s1 = s1.astype(np.float64)
+    lin = [0, 1, 3, 4, 5]
+    assert np.abs(s1[same][:, lin] - ref_state1[same][:, lin]).max() <= TOL_STATE
+    assert circ_diff(s1[same][:, 2], ref_state1[same][:, 2]).max() <= TOL_STATE
+    assert np.abs(out_obs[same] - ref_obs[same]).max() <= TOL_OBS
+    rel = np.abs(out_rew[same] - ref_rew[same]) / np.maximum(1.0, np.abs(ref_rew[same]))
+    assert rel.max() <= TOL_REWARD_REL, rel.max()
+
+
+@pytest.mark.parametrize("fam", list(FAMILIES))
+def test_step_matches_reference_golden(fam, golden_steps):
+    """Inject the fixture inputs, run ONE step without auto-reset, compare with what the reference produced."""
+    d = golden_steps[fam]
+    m = len(d["state0"])
+    env = make(FAMILIES[fam], m, seed=1, auto_reset=False)
+    env.reset()
+    is_goal = "planets" in d
+    env.set_state(ship=d["state0"], planets=d["planets"] if is_goal else None, goal=d["goal"] if is_goal else None,
+                  elapsed=np.zeros(m, np.int32))
+    obs, rew, done, info = env.step(d["action"])
+    st = env.get_state()
+    check_against(obs, rew, done, st["ship"], d["state1"], d["obs"], d["reward"], d["done"])
+    assert not info["TimeLimit.truncated"].any()
+    if is_goal:  # goal resampled exactly on the steps where the reference resampled it (goal.py:154-157)
+        changed = np.any(st["goal"] != d["goal"].astype(np.float32), axis=1)
+        assert np.array_equal(changed, d["goal_changed"].astype(bool))
+    assert np.array_equal(st["elapsed"], np.ones(m, np.int32))
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,n", [("GoalContinuous2P-v0", 4096), ("GoalContinuous3P-v0", 65536),
+                                      ("KeplerCircleOrbit-v0", 65536), ("GoalContinuous4P-v0", 65536),
+                                      ("KeplerEllipseHard-v0", 8192)])
+def test_rollout_steps_match_oracle(env_id, n):
+    """BASELINE.json configs at full batch: engine-generated states (own reset + auto-reset rollout), every step
+    re-checked against the oracle applied to the engine's own pre-step state."""
+    env = make(env_id, n, seed=7, auto_reset=True)
+    o = Oracle(env_id, threads=16)
+    env.reset()
+    rng = np.random.default_rng(11)
+    is_goal = env.spec["family"] == "goal"
+    for step in range(6):
+        # let episodes age (auto-reset keeps every env valid), then verify one step in detail
+        for _ in range(8 if step else 0):
+            env.step(rng.uniform(-1, 1, size=(n, 2)).astype(np.float32))
+        st = env.get_state()
+        a = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        obs, rew, done, info = env.step(a)
+        s1 = env.get_state()
+        ref = o.step(st["ship"].astype(np.float64), a, st["planets"].astype(np.float64) if is_goal else None,
+                     st["goal"].astype(np.float64) if is_goal else None)
+        trunc = info["TimeLimit.truncated"]
+        ref_done = ref["done"].astype(bool) | trunc
+        # finished envs were restarted inside the kernel: their last observation is in info["terminal_observation"],
+        # and the 7 leading observation slots ARE the terminal state (x, y, cos, sin, vx, vy, omega)
+        last_obs = np.where(done[:, None], info["terminal_observation"], obs)
+        ship1 = s1["ship"].astype(np.float64)
+        ship1[done] = ref["state1"][done]  # state of a restarted env is the new episode's; checked through last_obs
+        # a handful of envs sit within fp32 rounding of an event boundary at this batch size
+        check_against(last_obs, rew, done, ship1, ref["state1"], ref["obs"], ref["reward"], ref_done,
+                      allow_mismatch=max(2, n // 20000))
+        assert np.isfinite(obs).all() and np.isfinite(rew).all()
+        assert (s1["elapsed"][done] == 0).all() and (s1["elapsed"][~done] == st["elapsed"][~done] + 1).all()
+    env.close()
+
+
+def test_invariants_full_batch():
+    """Size-independent properties at B = 65536: theta in [0, 2pi], omega == 5 a1, a terminal state sits on
+    a boundary, observation layout, finite rewards, restarted envs are inside the world and clear of every planet."""
+    n = 65536
+    env = make("GoalContinuous3P-v0", n, seed=3)
+    env.reset()
+    rng = np.random.default_rng(5)
+    half = 1.5
+    R = 0.75 * (2 * np.sqrt(3) * 3.0 / (3 * 7)) * np.sqrt(3) / 2  # hexagonal_tiling.py:37,45-47,173 for the 3x3 tiling
+    n_done = 0
+    for _ in range(120):
+        a = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        planets0 = env.get_state()["planets"]
+        obs, rew, done, info = env.step(a)
+        st = env.get_state()
+        ship = st["ship"]
+        live = ~done
+        assert (ship[:, 2] >= 0).all() and (ship[:, 2] <= np.float32(2 * np.pi)).all()
+        assert np.array_equal(ship[live, 5], a[live, 1] * np.float32(5.0))  # dynamic_model.py:138-141
+        assert np.array_equal(obs[:, :2], ship[:, :2]) and np.array_equal(obs[:, 4:7], ship[:, 3:6])
+        assert np.allclose(obs[:, 2] ** 2 + obs[:, 3] ** 2, 1.0, atol=1e-5)
+        assert np.isfinite(rew).all() and np.isfinite(obs).all()
+        term = done & ~info["TimeLimit.truncated"]
+        if term.any():  # terminal observation = state at the event (scipy ivp.py:689-692): on a planet or a wall
+            tob = info["terminal_observation"][term]
+            dist = np.linalg.norm(planets0[term] - tob[:, None, :2], axis=2)
+            g = np.minimum(np.abs(dist - R).min(axis=1), np.abs(half - np.abs(tob[:, :2]).max(axis=1)))
+            assert g.max() < 2e-6, g.max()
+            assert np.array_equal(tob[:, 6], a[term, 1] * np.float32(5.0))
+        if done.any():  # first state of the next episode
+            s = ship[done]
+            assert (np.abs(s[:, :2]) < half - R / 2 + 1e-5).all()
+            clear = np.linalg.norm(st["planets"][done] - s[:, None, :2], axis=2).min(axis=1) - R
+            assert (clear > 0).all()
+            assert (np.abs(s[:, 5]) <= 4.2 + 1e-6).all() and (st["elapsed"][done] == 0).all()
+        n_done += int(done.sum())
+    assert n_done > n  # on average every env finished at least once
+    env.close()
+
+
+def test_time_limit_and_auto_reset():
+    """gym TimeLimit semantics (max_episode_steps, gym_space/__init__.py:29) + VectorEnv auto-reset."""
+    n, T = 4096, 5
+    env = make("KeplerCircleOrbit-v0", n, seed=2, max_episode_steps=T, auto_reset=True)
+    obs0 = env.reset()
+    zero = np.zeros((n, 2), np.float32)
+    zero[:, 0] = -1.0  # engine off
+    for t in range(1, T + 1):
+        obs, rew, done, info = env.step(zero)
+        trunc = info["TimeLimit.truncated"]
+        if t < T:
+            assert not trunc.any()
+            assert np.array_equal(env.get_state()["elapsed"][~done], np.full((~done).sum(), t, np.int32))
+        else:
+            assert np.array_equal(trunc | done, np.ones(n, bool)) and trunc.sum() > 0.9 * n
+            st = env.get_state()
+            assert (st["elapsed"] == 0).all()  # every env restarted
+            assert np.allclose(obs[:, :2], st["ship"][:, :2])  # obs is the first observation of the new episode
+            tob = info["terminal_observation"]
+            assert np.isfinite(tob[trunc]).all()
+            r = np.linalg.norm(st["ship"][:, :2], axis=1)
+            assert (r >= 0.7 - 1e-5).all() and (r <= 2.5 + 1e-5).all()  # kepler.py:235-237
+    # a different episode index gives a different start
+    assert not np.allclose(obs0[:, :2], obs[:, :2])
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0"])
+def test_reset_matches_oracle_sampler(env_id):
+    """Same counter-based RNG words on both sides: tile decisions are integer-exact, positions agree to fp32."""
+    n = 8192
+    env = make(env_id, n, seed=99, env_index_base=1000)
+    obs = env.reset()
+    st = env.get_state()
+    o = Oracle(env_id)
+    envs, oobs = o.vec_reset(n, seed=99, env_id0=1000)
+    assert np.abs(st["ship"] - envs["state"]).max() < 2e-6
+    assert np.abs(obs - oobs).max() < 5e-6
+    if st["planets"] is not None:
+        N = st["planets"].shape[1]
+        assert np.abs(st["planets"] - envs["planets_xy"][:, :N]).max() < 2e-6
+        assert np.abs(st["goal"] - envs["goal_xy"]).max() < 2e-6
+    env.close()
+
+
+def test_vector_env_trajectory_matches_oracle_vec_step():
+    """Whole VectorEnv semantics (step + goal resample + TimeLimit + auto-reset) against the oracle's vec_step for
+    100 steps from the same seed: states track within tolerance; envs whose discrete history diverged (an event
+    decided differently within fp32 rounding) are excluded and must be very few."""
+    env_id, n = "GoalContinuous3P-v0", 4096
+    env = make(env_id, n, seed=5, max_episode_steps=40)
+    o = Oracle(env_id, threads=8)
+    o.params.max_episode_steps = 40
+    obs = env.reset()
+    envs, oobs = o.vec_reset(n, seed=5)
+    rng = np.random.default_rng(1)
+    ok = np.ones(n, bool)
+    n_done = 0
+    for t in range(100):
+        a = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        obs, rew, done, info = env.step(a)
+        oobs, orew, odone, otrunc = o.vec_step(envs, a, seed=5)
+        ok &= (done == odone.astype(bool))
+        ok &= np.abs(obs - oobs).max(axis=1) < 1e-4  # errors compound over steps; single-step parity is tested above
+        assert np.array_equal(info["TimeLimit.truncated"][ok], otrunc.astype(bool)[ok])
+        n_done += int(done.sum())
+    assert n_done > n  # several generations of episodes went by
+    assert ok.mean() > 0.99, ok.mean()
+    env.close()
+
+
+def test_device_tensor_path_matches_host_path():
+    """sg_step_device on torch tensors (current stream) == sg_step on host arrays."""
+    import torch
+    n = 2048
+    a = np.random.default_rng(0).uniform(-1, 1, size=(4, n, 2)).astype(np.float32)
+    e1 = make("GoalContinuous3P-v0", n, seed=4)
+    e2 = make("GoalContinuous3P-v0", n, seed=4)
+    o1 = e1.reset()
+    o2 = e2.reset_torch().cpu().numpy()
+    assert np.array_equal(o1, o2)
+    at = torch.from_numpy(a).cuda()
+    K, D = 4, e2.obs_dim
+    obs = torch.empty((K, n, D), device="cuda"); rew = torch.empty((K, n), device="cuda")
+    done = torch.empty((K, n), dtype=torch.uint8, device="cuda"); trunc = torch.empty_like(done)
+    e2.rollout_torch(at, obs, rew, done, trunc)
+    torch.cuda.synchronize()
+    for t in range(K):
+        ob, rw, dn, info = e1.step(a[t])
+        assert np.array_equal(ob, obs[t].cpu().numpy()) and np.array_equal(rw, rew[t].cpu().numpy())
+        assert np.array_equal(dn, done[t].cpu().numpy().astype(bool))
+    e1.close(); e2.close()
+
+
+def test_sharding_is_invariant_to_the_split():
+    """Two handles with env_index_base 0 and B/2 reproduce one handle of B envs bit for bit (RNG keyed by global index)."""
+    n = 4096
+    full = make("GoalContinuous4P-v0", n, seed=8)
+    lo = make("GoalContinuous4P-v0", n // 2, seed=8, env_index_base=0)
+    hi = make("GoalContinuous4P-v0", n // 2, seed=8, env_index_base=n // 2)
+    assert np.array_equal(full.reset(), np.concatenate([lo.reset(), hi.reset()]))
+    rng = np.random.default_rng(2)
+    for _ in range(60):
+        a = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        of, rf, df, _ = full.step(a)
+        ol, rl, dl, _ = lo.step(a[: n // 2])
+        oh, rh, dh, _ = hi.step(a[n // 2:])
+        assert np.array_equal(of, np.concatenate([ol, oh])) and np.array_equal(rf, np.concatenate([rl, rh]))
+        assert np.array_equal(df, np.concatenate([dl, dh]))
+    for e in (full, lo, hi):
+        e.close()
