@@ -1,0 +1,164 @@
+"""CPU checks of the ENGINE's fp32 device math, compiled by g++ into a test-only host twin (tests/host_twin).
+The GPU runs the same source (space_gym_amd/csrc/sg_device.hpp) under hipcc; -m gpu tests repeat these checks on
+the card through the C ABI.  Tolerances are the ones stated for the engine."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import FAMILIES, ROOT, load_golden
+from oracle import Oracle
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "host_twin"))
+from pytwin import Twin  # noqa: E402
+
+TOL_STATE = 1e-5
+TOL_OBS = 1e-5
+TOL_REWARD_REL = 1e-5
+
+
+def circ_diff(a, b):
+    d = np.abs(a - b) % (2 * np.pi)
+    return np.minimum(d, 2 * np.pi - d)
+
+
+@pytest.mark.parametrize("fam", list(FAMILIES))
+def test_fp32_device_math_matches_reference_golden(fam, golden_steps):
+    d = golden_steps[fam]
+    r = Twin(FAMILIES[fam]).step(d["state0"], d["action"], d.get("planets"), d.get("goal"))
+    assert np.array_equal(r["done"], d["done"]) and np.array_equal(r["goal_hit"], d["goal_changed"])
+    # the engine runs scipy's RK45 controller in fp32: same number of accepted steps, same terminal event
+    assert np.array_equal(r["n_rk"], d["n_rk_steps"])
+    term = d["done"] == 1
+    assert np.array_equal(r["event"][term], d["event_index"][term])
+    assert np.abs(r["t"][term] - d["t_event"][term]).max() < 1e-6
+    s1 = r["state1"].astype(np.float64)
+    lin = [0, 1, 3, 4, 5]
+    assert np.abs(s1[:, lin] - d["state1"][:, lin]).max() <= TOL_STATE
+    assert circ_diff(s1[:, 2], d["state1"][:, 2]).max() <= TOL_STATE
+    assert np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
+    rel = np.abs(r["reward"] - d["reward"]) / np.maximum(1.0, np.abs(d["reward"]))
+    assert rel.max() <= TOL_REWARD_REL
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10, on the oracle and on the engine's device code."""
+    o, t = Oracle("GoalContinuous2P-v0"), Twin("GoalContinuous2P-v0")
+    kat = [((0, 0), (0, 0, 0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff, 0xffffffff), (0xffffffff,) * 4, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0xa4093822, 0x299f31d0), (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for key, ctr, want in kat:
+        assert tuple(o.philox(key, ctr)) == want
+        assert tuple(t.philox(key, ctr)) == want
+
+
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0",
+                                    "KeplerCircleOrbit-v0", "KeplerRandomOrbits-v0"])
+def test_reset_sampler_matches_oracle(env_id):
+    """Same counter RNG words -> identical tile decisions (integers), positions equal to fp32 rounding; also through
+    a chain of goal resamples (hexagonal_tiling.py:95-128)."""
+    n, hits = 4000, 6
+    o, t = Oracle(env_id), Twin(env_id)
+    tw = t.reset(n, seed=1234, env0=77, episode=0, n_hits=hits)
+    envs, _ = o.vec_reset(n, seed=1234, env_id0=77)
+    assert np.abs(tw["state"] - envs["state"]).max() < 2e-6
+    if env_id.startswith("Goal"):
+        N = o.n_planets
+        assert np.abs(tw["planets"] - envs["planets_xy"][:, :N]).max() < 2e-6
+        for k in range(hits + 1):
+            if k:
+                for i in range(n):
+                    o.resample_goal(envs, i, seed=1234, env_id0=77)
+            assert np.array_equal(tw["tiles"][:, k] & 0xff, envs["ship_tile"].astype(np.uint32))
+            assert np.array_equal((tw["tiles"][:, k] >> 8) & 0xff, envs["goal_tile"].astype(np.uint32))
+            assert np.abs(tw["goals"][:, k] - envs["goal_xy"]).max() < 2e-6
+            # free-tile multiset == the oracle's sorted list
+            counts = np.zeros((n, 16), np.int64)
+            for i in range(n):
+                for tile in envs["free_tiles"][i, :envs["n_free"][i]]:
+                    counts[i, tile] += 1
+            mine = (tw["free_counts"][:, k, None] >> (4 * np.arange(16, dtype=np.uint64))) & np.uint64(15)
+            assert np.array_equal(mine.astype(np.int64), counts)
+    elif "Random" in env_id:
+        assert np.abs(tw["orbit"][:, 0] - envs["orbit"][:, 0]).max() < 2e-6
+        assert np.abs(tw["orbit"][:, 1] - envs["orbit"][:, 1]).max() < 2e-6
+
+
+def chi2_ok(obs, exp, sigmas=5.0):
+    """Pearson chi-square of two count vectors (both sampled): |chi2 - dof| within `sigmas` of its spread."""
+    obs, exp = np.asarray(obs, float).ravel(), np.asarray(exp, float).ravel()
+    exp = exp * obs.sum() / exp.sum()
+    m = (obs + exp) > 20
+    chi2 = ((obs[m] - exp[m]) ** 2 / (obs[m] + exp[m])).sum()  # two-sample form
+    dof = m.sum() - 1
+    return abs(chi2 - dof) < sigmas * np.sqrt(2 * dof) + 5, (chi2, dof)
+
+
+@pytest.mark.parametrize("fam", ["goal2p", "goal3p", "goal4p"])
+def test_reset_distribution_matches_reference(fam):
+    """Distributional parity of the engine's reset + goal-resample chain with statistics of 1e5 resets of the reference
+    (GoalEnv._reset goal.py:133-145; HexagonalTiling hexagonal_tiling.py:53-134), tests/golden/reset_*.npz."""
+    ref = load_golden("reset_" + fam)
+    n, hits = int(ref["n_resets"]), int(ref["n_hits"])
+    t = Twin(FAMILIES[fam])
+    tw = t.reset(n, seed=4242, env0=0, episode=3, n_hits=hits)
+    half, nt = 1.5, len(ref["ship_tile"])
+    rows, cols = {"goal2p": (2, 2), "goal3p": (3, 3), "goal4p": (4, 4)}[fam]
+    assert nt == rows * cols
+    ship_tile, goal_tile = (tw["tiles"] & 0xff).astype(np.int64), ((tw["tiles"] >> 8) & 0xff).astype(np.int64)
+
+    def h2(xy):
+        return np.histogram2d(xy[:, 0], xy[:, 1], bins=24, range=[[-half, half]] * 2)[0]
+
+    ok, info = chi2_ok(h2(tw["state"][:, :2]), ref["ship_hist"]); assert ok, ("ship", info)
+    ok, info = chi2_ok(h2(tw["planets"].reshape(-1, 2)), ref["planets_hist"]); assert ok, ("planets", info)
+    ok, info = chi2_ok(np.bincount(ship_tile[:, 0], minlength=nt), ref["ship_tile"]); assert ok, ("ship tile", info)
+    flags = np.array([((tw["tiles"][:, 0] >> 16) & 1).sum(), ((tw["tiles"][:, 0] >> 17) & 1).sum()])
+    assert np.abs(flags / n - 0.5).max() < 0.01 and np.abs(ref["case_b_flip"] / n - 0.5).max() < 0.01
+    assert np.abs(tw["col_shift"][:, :cols].mean(0) - ref["col_shift_mean"]).max() < 5e-3
+    for k in range(hits + 1):
+        ok, info = chi2_ok(h2(tw["goals"][:, k]), ref["goal_hist"][k]); assert ok, ("goal", k, info)
+        ok, info = chi2_ok(np.bincount(goal_tile[:, k], minlength=nt), ref["goal_tile"][k]); assert ok, ("goal tile", k, info)
+        same = (goal_tile[:, k] == ship_tile[:, k]).mean()
+        assert abs(same - ref["same_tile"][k] / n) < 0.008, (k, same)
+        taxi = np.abs(goal_tile[:, k] // cols - ship_tile[:, k] // cols) + np.abs(goal_tile[:, k] % cols - ship_tile[:, k] % cols)
+        ok, info = chi2_ok(np.bincount(taxi, minlength=rows + cols), ref["taxi"][k]); assert ok, ("taxi", k, info)
+        free_len = ((tw["free_counts"][:, k, None] >> (4 * np.arange(16, dtype=np.uint64))) & np.uint64(15)).sum(1)
+        ok, info = chi2_ok(np.bincount(free_len.astype(int), minlength=ref["free_len"].shape[1]), ref["free_len"][k])
+        assert ok, ("free list length", k, info)
+        d = np.linalg.norm(tw["goals"][:, k] - tw["state"][:, :2], axis=1)
+        ok, info = chi2_ok(np.histogram(d, bins=30, range=(0, 4.5))[0], ref["ship_goal_dist_hist"][k]); assert ok, ("ship-goal", k, info)
+    kin = tw["state"]
+    ok, info = chi2_ok(np.histogram(kin[:, 2], bins=16, range=(0, 2 * np.pi))[0], ref["theta_hist"]); assert ok, ("theta", info)
+    ok, info = chi2_ok(np.histogram(kin[:, 3:5].ravel(), bins=32, range=(-0.35, 0.35))[0], ref["vel_hist"]); assert ok, ("vel", info)
+    ok, info = chi2_ok(np.histogram(kin[:, 5], bins=32, range=(-4.2 - 1e-9, 4.2 + 1e-9))[0], ref["omega_hist"]); assert ok, ("omega", info)
+    assert abs(kin[:, 3:5].std() - ref["vel_std"]) < 1e-3 and abs(kin[:, 5].std() - ref["omega_std"]) < 0.02
+    # clearances the tiling guarantees by construction: never tighter than what the reference ever produced - eps
+    R, rs = float(ref["planet_radius"]), float(ref["ship_radius"])
+    mc = dict(zip([str(k) for k in ref["min_clear_keys"]], ref["min_clear"]))
+    dist = np.linalg.norm(tw["planets"] - tw["state"][:, None, :2], axis=2).min(1) - R
+    assert dist.min() > rs - 1e-5 and mc["ship_planet"] > rs - 1e-9      # ship disc never overlaps a planet
+    assert (half - np.abs(tw["state"][:, :2]).max(1)).min() > rs - 1e-5 and mc["ship_wall"] > rs - 1e-9
+    assert (half - np.abs(tw["planets"]).max(2).min(1) - R).min() > -1e-5 and mc["planet_wall"] > -1e-9
+
+
+def test_kepler_reset_distribution_matches_reference():
+    """KeplerEnv._reset kepler.py:233-267."""
+    ref = load_golden("reset_kepler")
+    n = int(ref["n_resets"])
+    tw = Twin("KeplerCircleOrbit-v0").reset(n, seed=99, episode=1)
+    s = tw["state"]
+    rad = np.linalg.norm(s[:, :2], axis=1)
+    ang = np.arctan2(s[:, 1], s[:, 0]) % (2 * np.pi)
+    assert rad.min() >= 0.7 - 1e-6 and rad.max() <= 2.5 + 1e-6
+    for mine, theirs, name in [
+            (np.histogram(rad, bins=18, range=(0.7, 2.5))[0], ref["radius_hist"], "radius"),
+            (np.histogram(ang, bins=16, range=(0, 2 * np.pi))[0], ref["angle_hist"], "angle"),
+            (np.histogram(s[:, 2], bins=16, range=(0, 2 * np.pi))[0], ref["theta_hist"], "theta"),
+            (np.histogram(s[:, 3:5].ravel(), bins=32, range=(-0.25, 0.25))[0], ref["vel_hist"], "vel"),
+            (np.histogram(s[:, 5], bins=32, range=(-4.2 - 1e-9, 4.2 + 1e-9))[0], ref["omega_hist"], "omega")]:
+        ok, info = chi2_ok(mine, theirs)
+        assert ok, (name, info)
+    assert abs(s[:, 3:5].std() - ref["vel_std"]) < 1e-3 and abs(s[:, 5].std() - ref["omega_std"]) < 0.01
