@@ -28,12 +28,25 @@ def algorithmic_bytes_per_env_step(env_id):
     return 113 + 16 * s["n_planets"] if s["family"] == "goal" else 109
 
 
+def usable_cores():
+    """CPU share of this process: the cgroup quota when there is one (a 1-GPU box gets 16 of the host's cores),
+    else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 64)
+
+
 def cpu_baseline(env_id, batch, budget_s=12.0):
     """The fp64 CPU oracle (oracle/, a restatement of the reference's NumPy/scipy path pinned to its golden vectors)
     on the same workload, all host cores of this box, bounded sample.  Reported beside the GPU number, never as it."""
     import numpy as np
     from oracle import Oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     o = Oracle(env_id, threads=cores)
     n = min(batch, 65536)
     envs, _ = o.vec_reset(n, seed=0)

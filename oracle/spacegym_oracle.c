@@ -557,14 +557,6 @@ void sgo_philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-typedef struct { uint32_t s[4]; } xo128;
-static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
-static uint32_t xo_next(xo128 *g) { /* xoshiro128++ (Blackman, Vigna 2019) */
-    uint32_t *s = g->s, result = rotl32(s[0] + s[3], 7) + s[0], t = s[1] << 9;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-    s[2] ^= t; s[3] = rotl32(s[3], 11);
-    return result;
-}
 #define SGO_STREAM_RESET 0u
 #define SGO_STREAM_GOAL 1u
 static void stream_words(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t block, uint32_t stream, uint32_t out[4]) {
@@ -600,17 +592,20 @@ static void disc_in_tile(const sgo_params *p, const tiling_layout *L, int tile, 
     xy[1] += r * sin(angle);
 }
 
+/* Reset words (RNG): word k of an episode = component k%4 of Philox block k/4 of the reset stream.
+ *   Goal   block 0: flags, col01, col23, tiles01      block 1: tiles23, tiles45, goal_c01, goal_c2
+ *          block 2: disc_ship, disc_p0, disc_p1, disc_p2   block 3: disc_p3, disc_goal, theta, -
+ *          block 4: bm1_u1, bm1_u2, bm2_u1, bm2_u2
+ *   Kepler block 0: angle, dist, theta, ecc   block 1: orbit_angle, -, -, -   block 2: bm1_u1, bm1_u2, bm2_u1, bm2_u2 */
+static void reset_words(uint64_t seed, uint32_t env_id, uint32_t episode, int n_blocks, uint32_t *w) {
+    for (int b = 0; b < n_blocks; b++) stream_words(seed, env_id, episode, (uint32_t)b, SGO_STREAM_RESET, w + 4 * b);
+}
+
 /* The engine stores the per-episode layout; the oracle regenerates it from the reset stream (same words). */
-static void episode_layout(const sgo_params *p, uint64_t seed, uint32_t env_id, uint32_t episode, xo128 *g,
-                           uint32_t *flags_word, tiling_layout *L) {
-    uint32_t w[4];
-    stream_words(seed, env_id, episode, 0, SGO_STREAM_RESET, w);
-    memcpy(g->s, w, sizeof(w));
-    g->s[0] |= 1u; /* xoshiro state must not be all zero */
-    uint32_t f = xo_next(g);
-    *flags_word = f;
+static void episode_layout(const sgo_params *p, const uint32_t *w, tiling_layout *L) {
+    uint32_t f = w[0];
     L->case_b = f & 1u; L->flip = (f >> 1) & 1u;                 /* hexagonal_tiling.py:69 */
-    uint32_t c01 = xo_next(g), c23 = xo_next(g);
+    uint32_t c01 = w[1], c23 = w[2];
     double u[4] = {u16(c01 >> 16), u16(c01), u16(c23 >> 16), u16(c23)}, cum = 0;
     int cols = p->tiling_cols;
     double tiling_width = 3 * p->tiling_a * (cols - 1) / 2 + 2 * p->tiling_a; /* hexagonal_tiling.py:39 */
@@ -664,15 +659,16 @@ static void box_muller(uint32_t w1, uint32_t w2, double *z0, double *z1) {
 }
 
 void sgo_env_reset(const sgo_params *p, uint64_t seed, uint32_t env_id, sgo_env_state *e) {
-    xo128 g;
+    uint32_t w[20];
     e->elapsed = 0;
     e->goal_draws = 0;
     if (p->family == SGO_FAMILY_GOAL) {
         tiling_layout L;
-        uint32_t flags;
-        episode_layout(p, seed, env_id, e->episode, &g, &flags, &L);
+        reset_words(seed, env_id, e->episode, 5, w);
+        const uint32_t flags = w[0];
+        episode_layout(p, w, &L);
         int N = p->n_planets, T = p->tiling_rows * p->tiling_cols, tiles[SGO_MAX_PLANETS + 1];
-        uint32_t t01 = xo_next(&g), t23 = xo_next(&g), t45 = xo_next(&g);
+        uint32_t t01 = w[3], t23 = w[4], t45 = w[5];
         uint32_t draws[6] = {t01 >> 16, t01, t23 >> 16, t23, t45 >> 16, t45};
         if (N == 2 && ((flags >> 8) & 0xffu) < 64u) { /* hexagonal_tiling.py:75-87 */
             static const int diag[4][3] = {{1, 0, 3}, {2, 0, 3}, {0, 1, 2}, {3, 1, 2}};
@@ -694,34 +690,29 @@ void sgo_env_reset(const sgo_params *p, uint64_t seed, uint32_t env_id, sgo_env_
             if (!used) e->free_tiles[e->n_free++] = t;
         }
         double ship_radius = p->planet_radius[0] / 2; /* hexagonal_tiling.py:48 */
-        disc_in_tile(p, &L, tiles[0], ship_radius, xo_next(&g), e->state); /* :92-93 */
-        for (int j = 0; j < N; j++) disc_in_tile(p, &L, tiles[j + 1], p->planet_radius[j], xo_next(&g), e->planets_xy + 2 * j);
+        disc_in_tile(p, &L, tiles[0], ship_radius, w[8], e->state); /* :92-93 */
+        for (int j = 0; j < N; j++) disc_in_tile(p, &L, tiles[j + 1], p->planet_radius[j], w[9 + j], e->planets_xy + 2 * j);
         uint32_t gw[4];
-        gw[0] = flags >> 24; gw[1] = xo_next(&g); gw[2] = xo_next(&g); gw[3] = xo_next(&g);
+        gw[0] = flags >> 24; gw[1] = w[6]; gw[2] = w[7]; gw[3] = w[13];
         e->goal_tile = -1;
         choose_goal(p, &L, e, 1, gw); /* goal.py:138 */
         /* goal.py:140-145 */
-        e->state[2] = TWO_PI * (double)u23(xo_next(&g));
+        e->state[2] = TWO_PI * (double)u23(w[14]);
         double z0, z1, z2, z3;
-        uint32_t a = xo_next(&g), b = xo_next(&g);
-        box_muller(a, b, &z0, &z1);
-        a = xo_next(&g); b = xo_next(&g);
-        box_muller(a, b, &z2, &z3);
+        box_muller(w[16], w[17], &z0, &z1);
+        box_muller(w[18], w[19], &z2, &z3);
         e->state[3] = z0 * 0.07; e->state[4] = z1 * 0.07;
         double max_w = 0.7 * p->max_abs_vel_angle, om = z2 * max_w / 3;
         e->state[5] = fmin(fmax(om, -max_w), max_w);
         e->orbit[0] = e->orbit[1] = e->orbit[2] = 0;
     } else { /* kepler.py:233-267 */
-        uint32_t w[4];
-        stream_words(seed, env_id, e->episode, 0, SGO_STREAM_RESET, w);
-        memcpy(g.s, w, sizeof(w));
-        g.s[0] |= 1u;
-        double planet_angle = TWO_PI * (double)u23(xo_next(&g));
+        reset_words(seed, env_id, e->episode, 3, w);
+        double planet_angle = TWO_PI * (double)u23(w[0]);
         double lo = p->planet_radius[0] + 0.5, hi = p->planet_radius[1] - 0.5;
-        double dist = lo + (hi - lo) * (double)u23(xo_next(&g));
+        double dist = lo + (hi - lo) * (double)u23(w[1]);
         e->state[0] = cos(planet_angle) * dist; e->state[1] = sin(planet_angle) * dist;
-        e->state[2] = TWO_PI * (double)u23(xo_next(&g));
-        uint32_t we = xo_next(&g), wa = xo_next(&g);
+        e->state[2] = TWO_PI * (double)u23(w[2]);
+        uint32_t we = w[3], wa = w[4];
         if (p->randomize_orbit) { /* kepler.py:257-259 (global np.random in the reference) */
             e->orbit[1] = (double)u23(we) * 0.7;
             e->orbit[0] = (double)u23(wa) * 2 * 3.141592653589793;
@@ -730,10 +721,8 @@ void sgo_env_reset(const sgo_params *p, uint64_t seed, uint32_t env_id, sgo_env_
         }
         e->orbit[2] = p->ref_orbit_a;
         double z0, z1, z2, z3;
-        uint32_t a = xo_next(&g), b = xo_next(&g);
-        box_muller(a, b, &z0, &z1);
-        a = xo_next(&g); b = xo_next(&g);
-        box_muller(a, b, &z2, &z3);
+        box_muller(w[8], w[9], &z0, &z1);
+        box_muller(w[10], w[11], &z2, &z3);
         e->state[3] = z0 * 0.05; e->state[4] = z1 * 0.05;
         double max_w = 0.7 * p->max_abs_vel_angle, om = z2 * max_w / 5;
         e->state[5] = fmin(fmax(om, -max_w), max_w);
@@ -744,10 +733,10 @@ void sgo_env_reset(const sgo_params *p, uint64_t seed, uint32_t env_id, sgo_env_
 }
 
 void sgo_env_resample_goal(const sgo_params *p, uint64_t seed, uint32_t env_id, sgo_env_state *e) {
-    xo128 g;
     tiling_layout L;
-    uint32_t flags, w[4];
-    episode_layout(p, seed, env_id, e->episode, &g, &flags, &L);
+    uint32_t w[4], w0[4];
+    stream_words(seed, env_id, e->episode, 0, SGO_STREAM_RESET, w0);
+    episode_layout(p, w0, &L);
     e->goal_draws += 1;
     stream_words(seed, env_id, e->episode, e->goal_draws, SGO_STREAM_GOAL, w);
     choose_goal(p, &L, e, 0, w);

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspacegym_hip.so")
+# SPACEGYM_LIB points at another build of the SAME library (e.g. the stamped diagnostic build); never at a CPU path
+LIB_PATH = os.environ.get("SPACEGYM_LIB") or os.path.join(_HERE, "lib", "libspacegym_hip.so")
 _lib = None
 
 

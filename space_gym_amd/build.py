@@ -34,15 +34,17 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not is_stale():
+def build(force=False, verbose=False, extra=(), out=None):
+    """out=None builds the product library; a different `out` (with e.g. extra=("-DSG_STAMPS",)) a diagnostic one."""
+    if out is None and not force and not is_stale():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), *flags(extra), "-o", LIB, *[os.path.join(CSRC, f) for f in SOURCES]]
+    out = out or LIB
+    cmd = [hipcc(), *flags(extra), "-o", out, *[os.path.join(CSRC, f) for f in SOURCES]]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -317,48 +317,67 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
                 q2[i] = fmaf(P72, d6_, fmaf(P62, d5_, fmaf(P52, d4_, fmaf(P42, d3_, P32 * d2_))));
                 q3[i] = fmaf(P73, d6_, fmaf(P63, d5_, fmaf(P53, d4_, fmaf(P43, d3_, P33 * d2_))));
             }
-            auto disp = [&](int i, float s) { return h * s * fmaf(s, fmaf(s, fmaf(s, q3[i], q2[i]), q1[i]), k0[i]); };
-            auto dispd = [&](int i, float s) {  // d disp / ds
+            auto disp = [&](int i, float s) __attribute__((always_inline)) { return h * s * fmaf(s, fmaf(s, fmaf(s, q3[i], q2[i]), q1[i]), k0[i]); };
+            auto dispd = [&](int i, float s) __attribute__((always_inline)) {  // d disp / ds
                 return h * fmaf(s, fmaf(s, fmaf(4.0f * s, q3[i], 3.0f * q2[i]), 2.0f * q1[i]), k0[i]);
             };
+            // Every event function is solved through SMOOTH components: a circle is one component; a wall event
+            // min(W/2 -+ x, W/2 -+ y) (dynamic_model.py:196-205) has a kink, so its x and y parts are solved separately
+            // and combined by the min semantics: leaving the world (g: + -> -) the first component to cross wins,
+            // entering it (g: - -> +, injected states only) the last one does.
             float best = 2.0f;
-            int best_k = -1;
+            int best_k = -1, best_comp = 0;
             float bax = 0.0f, bay = 0.0f;  // absolute centre of the winning circle event
             double bRd = 0.0;
             unsigned m = mask;
             while (m) {  // usually one active event; all are terminal -> the earliest root wins (ivp.py:115-126)
-                int k = __builtin_ctz(m);
+                const int k = __builtin_ctz(m);
                 m &= m - 1;
                 // per-lane event description (selects, no dynamic register indexing)
-                float ecx = 0.0f, ecy = 0.0f, eR = 0.0f, eax = 0.0f, eay = 0.0f, ga = 0.0f, gb = 0.0f;
+                float ecx = 0.0f, ecy = 0.0f, eR = 0.0f, eax = 0.0f, eay = 0.0f, g0 = 0.0f, g1 = 0.0f;
                 double eRd = 0.0;
 #pragma unroll
                 for (int j = 0; j < NC + (WALLS ? 2 : 0); j++)
                     if (j == k) {
-                        ga = g[j]; gb = gn[j];
+                        g0 = g[j]; g1 = gn[j];
                         if (j < NC) { ecx = cqx[j]; ecy = cqy[j]; eR = cR[j]; eax = cax[j]; eay = cay[j]; eRd = cRd[j]; }
                     }
-                const bool circle = k < NC, wmax = (k == NC);
-                auto gfun = [&](float s) {
-                    float dx = X + disp(0, s), dy = Y + disp(1, s);
-                    float ex = ecx - dx, ey = ecy - dy;
-                    float gc = fsqrt(fmaf(ex, ex, ey * ey)) - eR;
-                    float gw = wmax ? fminf(wxp - dx, wyp - dy) : fminf(wxm + dx, wym + dy);
-                    return circle ? gc : gw;
-                };
-                // Illinois (modified regula falsi) on the bracket [0, 1]
-                float a = 0.0f, b = 1.0f;
-                for (int it = 0; it < kRootIters; it++) {
-                    float den = gb - ga;
-                    float c = (den == 0.0f) ? b : b - gb * (b - a) * rcp(den);
-                    c = fminf(fmaxf(c, 0.0f), 1.0f);
-                    float gc = gfun(c);
-                    if (gc * gb < 0.0f) { a = b; ga = gb; } else { ga *= 0.5f; }
-                    b = c; gb = gc;
+                const bool circle = k < NC, leaving = g0 > 0.0f;
+                const float sgn = (k == NC) ? 1.0f : -1.0f;                      // world_max : world_min
+                const float wx = (k == NC) ? wxp : wxm, wy = (k == NC) ? wyp : wym;
+                float root = leaving ? 2.0f : -1.0f;
+                int root_comp = 0;
+                for (int comp = 0; comp < (WALLS ? 2 : 1); comp++) {
+                    if (circle && comp == 1) continue;
+                    float ga, gb;
+                    if (circle) { ga = g0; gb = g1; }
+                    else {
+                        ga = comp ? wy - sgn * Y : wx - sgn * X;
+                        gb = comp ? wy - sgn * Yn : wx - sgn * Xn;
+                        if (!((ga <= 0.0f && gb >= 0.0f) || (ga >= 0.0f && gb <= 0.0f))) continue;  // this part does not cross
+                    }
+                    auto gfun = [&](float s) __attribute__((always_inline)) {
+                        float dx = X + disp(0, s), dy = Y + disp(1, s);
+                        float ex = ecx - dx, ey = ecy - dy;
+                        float gc = fsqrt(fmaf(ex, ex, ey * ey)) - eR;
+                        float gw = comp ? wy - sgn * dy : wx - sgn * dx;
+                        return circle ? gc : gw;
+                    };
+                    // Illinois (modified regula falsi) on the bracket [0, 1]
+                    float a = 0.0f, b = 1.0f;
+                    for (int it = 0; it < kRootIters; it++) {
+                        float den = gb - ga;
+                        float c = (den == 0.0f) ? b : b - gb * (b - a) * rcp(den);
+                        c = fminf(fmaxf(c, 0.0f), 1.0f);
+                        float gc = gfun(c);
+                        if (gc * gb < 0.0f) { a = b; ga = gb; } else { ga *= 0.5f; }
+                        b = c; gb = gc;
+                    }
+                    if (leaving ? (b < root) : (b > root)) { root = b; root_comp = comp; }
                 }
-                if (b < best) { best = b; best_k = k; bax = eax; bay = eay; bRd = eRd; }
+                if (root < best && root >= 0.0f) { best = root; best_k = k; best_comp = root_comp; bax = eax; bay = eay; bRd = eRd; }
             }
-            // One Newton step on the winning event with g evaluated in fp64 from the unrounded inputs: the Goal
+            // One Newton step on the winning component with g evaluated in fp64 from the unrounded inputs: the Goal
             // reward multiplies the terminal position by up to 1000 (goal.py:147-152), so fp32 noise in g (~1e-7)
             // would show.  The slope only needs a few digits.
             {
@@ -372,10 +391,9 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
                     gd = r2 * ir - bRd;
                     gp = -((float)ex * ux + (float)ey * uy) * (float)ir;
                 } else {
-                    const double sgn = (best_k == NC) ? 1.0 : -1.0, hw = (double)half_world;
-                    const double gx_ = hw - sgn * ((double)x0 + (double)dx), gy_ = hw - sgn * ((double)y0 + (double)dy);
-                    gd = gx_ < gy_ ? gx_ : gy_;
-                    gp = (float)(-sgn) * (gx_ < gy_ ? ux : uy);
+                    const double sg = (best_k == NC) ? 1.0 : -1.0, hw = (double)half_world;
+                    gd = best_comp ? hw - sg * ((double)y0 + (double)dy) : hw - sg * ((double)x0 + (double)dx);
+                    gp = (float)(-sg) * (best_comp ? uy : ux);
                 }
                 if (fabsf(gp) > 1e-12f) best = fminf(fmaxf(s - (float)gd * rcp(gp), 0.0f), 1.0f);
             }
@@ -524,18 +542,13 @@ SG_FN void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uin
 
 constexpr uint32_t kStreamReset = 0u, kStreamGoal = 1u;
 
-struct Xo128 {
-    uint32_t s0, s1, s2, s3;
-    SG_MFN uint32_t next() {  // xoshiro128++ (Blackman & Vigna)
-        uint32_t r = s0 + s3;
-        r = ((r << 7) | (r >> 25)) + s0;
-        uint32_t t = s1 << 9;
-        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
-        s2 ^= t;
-        s3 = (s3 << 11) | (s3 >> 21);
-        return r;
-    }
-};
+// Reset words (RNG): word k of an episode = component k%4 of Philox block k/4 of the reset stream, so the
+// blocks can be generated by different lanes at once (cooperative restart in sg_engine.hip) or one after the other.
+//   Goal   block 0: flags, col01, col23, tiles01            block 1: tiles23, tiles45, goal_c01, goal_c2
+//          block 2: disc_ship, disc_p0, disc_p1, disc_p2    block 3: disc_p3, disc_goal, theta, -
+//          block 4: bm1_u1, bm1_u2, bm2_u1, bm2_u2
+//   Kepler block 0: angle, dist, theta, ecc   block 1: orbit_angle, -, -, -   block 2: bm1_u1, bm1_u2, bm2_u1, bm2_u2
+constexpr int kGoalResetBlocks = 5, kKeplerResetBlocks = 3;
 
 SG_FN float u23(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }       // (0,1), exact
 SG_FN float u16(uint32_t h) { return ((float)(h & 0xffffu) + 0.5f) * (1.0f / 65536.0f); }    // (0,1), exact
@@ -550,7 +563,7 @@ struct Tiling {
     uint32_t episode, goal_draws;
     uint32_t ship_tile, goal_tile, case_b, flip;
     uint64_t free_counts;
-    float col_shift[4];
+    float cs0, cs1, cs2, cs3;  // column shifts; scalars, not an array: a runtime-indexed member would push the struct to scratch
 };
 
 SG_FN uint32_t free_total(uint64_t f) {
@@ -577,10 +590,7 @@ SG_FN uint64_t free_remove(uint64_t f, uint32_t tile) { return f - (1ull << (4 *
 // hexagonal_tiling.py:136-158 _tile_center_pos
 SG_FN void tile_center(const SgDev &c, const Tiling &T, uint32_t tile, float &x, float &y) {
     uint32_t row = tile / (uint32_t)c.t_cols, col = tile - row * (uint32_t)c.t_cols;
-    float shift = T.col_shift[0];
-#pragma unroll
-    for (uint32_t j = 1; j < 4; j++)
-        if (j == col) shift = T.col_shift[j];
+    const float shift = (col == 1u) ? T.cs1 : (col == 2u) ? T.cs2 : (col == 3u) ? T.cs3 : T.cs0;
     float tx = c.t_x0 + (float)col * 1.5f * c.t_a + shift;
     float y0 = T.case_b ? c.t_y0 - 0.5f * c.t_hex_h : c.t_y0;
     float ycol = (col & 1u) ? 0.5f * c.t_hex_h : 0.0f;
@@ -599,8 +609,8 @@ SG_FN void disc_in_tile(const SgDev &c, const Tiling &T, uint32_t tile, float no
     y = fmaf(r, s, y);
 }
 
-// hexagonal_tiling.py:99-128 _reset_goal_tile_nr + :95-97 find_new_goal.  w = [gate, cand0:cand1, cand2:-, disc]
-SG_FN void choose_goal(const SgDev &c, Tiling &T, bool first, const uint32_t (&w)[4], float &gx, float &gy) {
+// hexagonal_tiling.py:99-128 _reset_goal_tile_nr.  w = [gate, cand0:cand1, cand2:-, disc]
+SG_FN void choose_goal_tile(const SgDev &c, Tiling &T, bool first, const uint32_t (&w)[4]) {
     if (!first) {  // :101-106 the ship now sits on the tile of the goal it reached
         T.free_counts = free_add(T.free_counts, T.ship_tile);
         T.ship_tile = T.goal_tile;
@@ -629,15 +639,23 @@ SG_FN void choose_goal(const SgDev &c, Tiling &T, bool first, const uint32_t (&w
         }
         uint32_t best_tile = 0;
         int best_dist = -1;
-        for (uint32_t i = 0; i < n_cand; i++) {
-            uint32_t tile = free_at(T.free_counts, chosen[i]);
-            uint32_t r = tile / cols, cc = tile - r * cols;
-            int dist = abs((int)r - (int)sr) + abs((int)cc - (int)sc);  // :119-121
-            if (dist > best_dist) { best_dist = dist; best_tile = tile; }  // first max, :122-124
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) {  // fully unrolled: keeps chosen[] in registers
+            if (i < n_cand) {
+                uint32_t tile = free_at(T.free_counts, chosen[i]);
+                uint32_t r = tile / cols, cc = tile - r * cols;
+                int dist = abs((int)r - (int)sr) + abs((int)cc - (int)sc);  // :119-121
+                if (dist > best_dist) { best_dist = dist; best_tile = tile; }  // first max, :122-124
+            }
         }
         T.goal_tile = best_tile;
         T.free_counts = free_remove(T.free_counts, best_tile);  // pop, :126
     }
+}
+
+// hexagonal_tiling.py:95-97 find_new_goal: goal tile, then a uniform disc inside it (:130-134)
+SG_FN void choose_goal(const SgDev &c, Tiling &T, bool first, const uint32_t (&w)[4], float &gx, float &gy) {
+    choose_goal_tile(c, T, first, w);
     disc_in_tile(c, T, T.goal_tile, c.noise_goal, w[3], gx, gy);
 }
 
@@ -652,69 +670,79 @@ SG_FN void box_muller(uint32_t w1, uint32_t w2, float &z0, float &z1) {
 struct ShipInit { float x, y, th, vx, vy, om; };
 
 // GoalEnv._reset (goal.py:133-145) + HexagonalTiling.reset (hexagonal_tiling.py:53-93)
+// Pieces of GoalEnv._reset (goal.py:133-145) + HexagonalTiling.reset (hexagonal_tiling.py:53-93), shared by the serial
+// reset below and the lane-cooperative restart in sg_engine.hip.
+SG_FN void layout_from_words(const SgDev &c, uint32_t flags, uint32_t c01, uint32_t c23, Tiling &T) {
+    T.case_b = flags & 1u; T.flip = (flags >> 1) & 1u;  // hexagonal_tiling.py:69
+    // :70 cumsum over the first t_cols (2..4) columns
+    const float a0 = u16(c01 >> 16), a1 = a0 + u16(c01);
+    const float a2 = (c.t_cols > 2) ? a1 + u16(c23 >> 16) : a1, a3 = (c.t_cols > 3) ? a2 + u16(c23) : a2;
+    const float k = c.t_free_x * rcp(a3);  // :71-72 (a3 is the last real column's cumulative sum)
+    T.cs0 = a0 * k; T.cs1 = a1 * k;
+    T.cs2 = (c.t_cols > 2) ? a2 * k : 0.0f; T.cs3 = (c.t_cols > 3) ? a3 * k : 0.0f;
+}
+
+// tiles[0] = ship, tiles[1..N] = planets; also the free-tile multiset and T.ship_tile
+template <int N>
+SG_FN void tiles_from_words(const SgDev &c, uint32_t flags, uint32_t t01, uint32_t t23, uint32_t t45, Tiling &T,
+                            uint32_t (&tiles)[N + 1]) {
+    const uint32_t draws[6] = {t01 >> 16, t01, t23 >> 16, t23, t45 >> 16, t45};
+    // choice(n_tiles, size=N+1, replace=False) (:89): Fisher-Yates on a 16-nibble permutation word
+    uint64_t perm = 0xfedcba9876543210ull;
+    const uint32_t nt = (uint32_t)c.t_tiles;
+#pragma unroll
+    for (uint32_t i = 0; i <= (uint32_t)N; i++) {
+        uint32_t j = i + below16(draws[i], nt - i);
+        uint64_t vi = (perm >> (4 * i)) & 15ull, vj = (perm >> (4 * j)) & 15ull;
+        perm = (perm & ~((15ull << (4 * i)) | (15ull << (4 * j)))) | (vj << (4 * i)) | (vi << (4 * j));
+        tiles[i] = (uint32_t)vj;
+    }
+    if (N == 2 && ((flags >> 8) & 0xffu) < 64u) {  // :75-87 the four diagonal layouts, w.p. 0.25
+        const uint32_t d = (flags >> 16) & 3u;
+        tiles[0] = (d == 0) ? 1u : (d == 1) ? 2u : (d == 2) ? 0u : 3u;
+        tiles[1] = (d < 2) ? 0u : 1u;
+        tiles[2] = (d < 2) ? 3u : 2u;
+    }
+    uint64_t used = 0;
+#pragma unroll
+    for (int i = 0; i <= N; i++) used |= 1ull << (4 * tiles[i]);
+    const uint64_t all = (nt >= 16u) ? 0x1111111111111111ull : (0x1111111111111111ull & ((1ull << (4 * nt)) - 1ull));
+    T.free_counts = all & ~used;  // :91
+    T.ship_tile = tiles[0];       // :90
+}
+
+SG_FN void kinematics_from_words(const SgDev &c, uint32_t wth, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, ShipInit &s) {
+    s.th = kTwoPi * u23(wth);  // goal.py:140
+    float z0, z1, z2, z3;
+    box_muller(b0, b1, z0, z1);
+    box_muller(b2, b3, z2, z3);
+    s.vx = z0 * c.vel_std; s.vy = z1 * c.vel_std;                               // goal.py:141 / kepler.py:261
+    s.om = fminf(fmaxf(z2 * c.omega_std, -c.omega_max), c.omega_max);           // goal.py:142-144 / kepler.py:263-265
+}
+
+// GoalEnv._reset, one lane does everything (reset kernel, host twin)
 template <int N>
 SG_FN void goal_reset(const SgDev &c, uint32_t env_global, Tiling &T, ShipInit &s, float (&px)[N], float (&py)[N],
                       float &gx, float &gy) {
-    uint32_t w[4];
-    philox4x32_10(c.seed_lo, c.seed_hi, env_global, T.episode, 0u, kStreamReset, w);
-    Xo128 g = {w[0] | 1u, w[1], w[2], w[3]};
+    uint32_t w[4 * kGoalResetBlocks];
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)kGoalResetBlocks; b++) {
+        uint32_t o[4];
+        philox4x32_10(c.seed_lo, c.seed_hi, env_global, T.episode, b, kStreamReset, o);
+        w[4 * b] = o[0]; w[4 * b + 1] = o[1]; w[4 * b + 2] = o[2]; w[4 * b + 3] = o[3];
+    }
     T.goal_draws = 0;
-    const uint32_t flags = g.next();
-    T.case_b = flags & 1u; T.flip = (flags >> 1) & 1u;  // hexagonal_tiling.py:69
-    {
-        const uint32_t c01 = g.next(), c23 = g.next();
-        const float u[4] = {u16(c01 >> 16), u16(c01), u16(c23 >> 16), u16(c23)};
-        float cum = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {  // :70 cumsum over the first t_cols columns
-            if (j < c.t_cols) cum += u[j];
-            T.col_shift[j] = (j < c.t_cols) ? cum : 0.0f;
-        }
-        const float k = c.t_free_x * rcp(cum);  // :71-72
-#pragma unroll
-        for (int j = 0; j < 4; j++) T.col_shift[j] *= k;
-    }
+    const uint32_t flags = w[0];
+    layout_from_words(c, flags, w[1], w[2], T);
     uint32_t tiles[N + 1];
-    {
-        const uint32_t t01 = g.next(), t23 = g.next(), t45 = g.next();
-        const uint32_t draws[6] = {t01 >> 16, t01, t23 >> 16, t23, t45 >> 16, t45};
-        // choice(n_tiles, size=N+1, replace=False) (:89): Fisher-Yates on a 16-nibble permutation word
-        uint64_t perm = 0xfedcba9876543210ull;
-        const uint32_t nt = (uint32_t)c.t_tiles;
+    tiles_from_words<N>(c, flags, w[3], w[4], w[5], T, tiles);
+    disc_in_tile(c, T, tiles[0], c.noise_ship, w[8], s.x, s.y);  // :92-93
 #pragma unroll
-        for (uint32_t i = 0; i <= (uint32_t)N; i++) {
-            uint32_t j = i + below16(draws[i], nt - i);
-            uint64_t vi = (perm >> (4 * i)) & 15ull, vj = (perm >> (4 * j)) & 15ull;
-            perm = (perm & ~((15ull << (4 * i)) | (15ull << (4 * j)))) | (vj << (4 * i)) | (vi << (4 * j));
-            tiles[i] = (uint32_t)vj;
-        }
-        if (N == 2 && ((flags >> 8) & 0xffu) < 64u) {  // :75-87 the four diagonal layouts, w.p. 0.25
-            const uint32_t d = (flags >> 16) & 3u;
-            tiles[0] = (d == 0) ? 1u : (d == 1) ? 2u : (d == 2) ? 0u : 3u;
-            tiles[1] = (d < 2) ? 0u : 1u;
-            tiles[2] = (d < 2) ? 3u : 2u;
-        }
-        uint64_t used = 0;
-#pragma unroll
-        for (int i = 0; i <= N; i++) used |= 1ull << (4 * tiles[i]);
-        const uint64_t all = (nt >= 16u) ? 0x1111111111111111ull : (0x1111111111111111ull & ((1ull << (4 * nt)) - 1ull));
-        T.free_counts = all & ~used;  // :91
-    }
-    T.ship_tile = tiles[0];  // :90
-    disc_in_tile(c, T, tiles[0], c.noise_ship, g.next(), s.x, s.y);  // :92-93
-#pragma unroll
-    for (int j = 0; j < N; j++) disc_in_tile(c, T, tiles[j + 1], c.noise_planet, g.next(), px[j], py[j]);
-    {
-        const uint32_t gw[4] = {flags >> 24, g.next(), g.next(), g.next()};
-        T.goal_tile = 0xffu;
-        choose_goal(c, T, true, gw, gx, gy);  // goal.py:138
-    }
-    s.th = kTwoPi * u23(g.next());  // goal.py:140
-    float z0, z1, z2, z3;
-    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z0, z1); }
-    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z2, z3); }
-    s.vx = z0 * c.vel_std; s.vy = z1 * c.vel_std;                               // goal.py:141
-    s.om = fminf(fmaxf(z2 * c.omega_std, -c.omega_max), c.omega_max);           // goal.py:142-144
+    for (int j = 0; j < N; j++) disc_in_tile(c, T, tiles[j + 1], c.noise_planet, w[9 + j], px[j], py[j]);
+    const uint32_t gw[4] = {flags >> 24, w[6], w[7], w[13]};
+    T.goal_tile = 0xffu;
+    choose_goal(c, T, true, gw, gx, gy);  // goal.py:138
+    kinematics_from_words(c, w[14], w[16], w[17], w[18], w[19], s);
 }
 
 // GoalEnv._resample_goal on a hit (goal.py:154-157 -> hexagonal_tiling.py:95-134)
@@ -727,21 +755,19 @@ SG_FN void goal_resample(const SgDev &c, uint32_t env_global, Tiling &T, float &
 
 // KeplerEnv._reset (kepler.py:233-267)
 SG_FN void kepler_reset(const SgDev &c, uint32_t env_global, uint32_t episode, ShipInit &s, float &phi, float &ecc) {
-    uint32_t w[4];
-    philox4x32_10(c.seed_lo, c.seed_hi, env_global, episode, 0u, kStreamReset, w);
-    Xo128 g = {w[0] | 1u, w[1], w[2], w[3]};
+    uint32_t w[4 * kKeplerResetBlocks];
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)kKeplerResetBlocks; b++) {
+        uint32_t o[4];
+        philox4x32_10(c.seed_lo, c.seed_hi, env_global, episode, b, kStreamReset, o);
+        w[4 * b] = o[0]; w[4 * b + 1] = o[1]; w[4 * b + 2] = o[2]; w[4 * b + 3] = o[3];
+    }
     float sa, ca;
-    sincos_acc(kTwoPi * u23(g.next()), sa, ca);
-    float dist = fmaf(c.kep_rmax - c.kep_rmin, u23(g.next()), c.kep_rmin);
+    sincos_acc(kTwoPi * u23(w[0]), sa, ca);
+    float dist = fmaf(c.kep_rmax - c.kep_rmin, u23(w[1]), c.kep_rmin);
     s.x = ca * dist; s.y = sa * dist;
-    s.th = kTwoPi * u23(g.next());
-    const uint32_t we = g.next(), wa = g.next();
-    if (c.randomize_orbit) { ecc = u23(we) * 0.7f; phi = u23(wa) * kTwoPi; }    // kepler.py:257-259
-    float z0, z1, z2, z3;
-    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z0, z1); }
-    { uint32_t a = g.next(), b = g.next(); box_muller(a, b, z2, z3); }
-    s.vx = z0 * c.vel_std; s.vy = z1 * c.vel_std;
-    s.om = fminf(fmaxf(z2 * c.omega_std, -c.omega_max), c.omega_max);
+    if (c.randomize_orbit) { ecc = u23(w[3]) * 0.7f; phi = u23(w[4]) * kTwoPi; }    // kepler.py:257-259
+    kinematics_from_words(c, w[2], w[8], w[9], w[10], w[11], s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -88,7 +88,7 @@ static void goal_resets(const SgDev &c, int64_t m, uint32_t env0, uint32_t episo
             tiles[i * (n_hits + 1) + k] = T.ship_tile | (T.goal_tile << 8) | (T.case_b << 16) | (T.flip << 17);
             free_counts[i * (n_hits + 1) + k] = T.free_counts;
         }
-        std::memcpy(col_shift + 4 * i, T.col_shift, sizeof(T.col_shift));
+        col_shift[4 * i] = T.cs0; col_shift[4 * i + 1] = T.cs1; col_shift[4 * i + 2] = T.cs2; col_shift[4 * i + 3] = T.cs3;
     }
 }
 
