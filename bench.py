@@ -28,6 +28,18 @@ def algorithmic_bytes_per_env_step(env_id):
     return 113 + 16 * s["n_planets"] if s["family"] == "goal" else 109
 
 
+def measured_traffic(env_id, batch):
+    """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 for 16 B/lane streams, WRITE_SIZE), taken
+    offline with tools/gpu_profile.sh and committed under profiles/; null when no measurement matches this workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if t.get("env_id") == env_id and t.get("batch") == batch:
+            return t["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def usable_cores():
     """CPU share of this process: the cgroup quota when there is one (a 1-GPU box gets 16 of the host's cores),
     else the affinity mask."""
@@ -123,25 +135,30 @@ def main():
         env.rollout_torch(act_seq[:W], obs[:W], rew[:W], done[:W], trunc[:W])
     sync_all()
 
-    # ---- timed region: exactly K steps, kernel durations taken from start/stop events on each dispatch
+    # ---- timed region: exactly K steps, no instrumentation; one HIP event pair on the launch stream brackets it
     timing = not args.no_kernel_timing
-    env.set_profiling(timing)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync_all()
     t0 = time.perf_counter()
+    ev0.record()  # torch's current stream == the stream rollout_torch launches on
     env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+    ev1.record()
     sync_all()
     dt = time.perf_counter() - t0
-    launches, kern_ms, kmin, kmax = env.get_profile() if timing else (0, 0.0, 0.0, 0.0)
-    env.set_profiling(False)
+    stream_ms_per_launch = ev0.elapsed_time(ev1) / K  # kernel + inter-kernel gap
 
-    # ---- untimed A/B: the same K steps without per-dispatch events, to show what the instrumentation costs
-    dt_plain = None
+    # ---- the same K steps again with start/stop events on every dispatch (hipExtLaunchKernelGGL): the kernel's own
+    # duration, as rocprofv3 --kernel-trace reports it.  Costs ~35% throughput, hence not done in the region above.
+    launches, kern_ms, kmin, kmax, dt_events = 0, 0.0, 0.0, 0.0, None
     if timing:
+        env.set_profiling(True)
         sync_all()
         t1 = time.perf_counter()
         env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
         sync_all()
-        dt_plain = time.perf_counter() - t1
+        dt_events = time.perf_counter() - t1
+        launches, kern_ms, kmin, kmax = env.get_profile()
+        env.set_profiling(False)
 
     gather_ms = None
     if args.gather and world > 1:
@@ -182,12 +199,15 @@ def main():
             avg_us = kern_ms * 1e3 / launches
             achieved = B * bytes_per / (avg_us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.env, B),
                                "kernel": "goal_step_kernel<3>" if args.env == "GoalContinuous3P-v0" else "step kernel",
                                "kernel_avg_us": avg_us, "kernel_min_us": kmin * 1e3, "kernel_max_us": kmax * 1e3,
-                               "launches": launches, "algorithmic_bytes_per_env_step": bytes_per,
+                               "launches": launches, "timing": "hipExtLaunchKernelGGL start/stop events on each of the "
+                               f"{launches} dispatches of a second, identical {K}-step pass",
+                               "stream_event_us_per_launch_in_timed_region": stream_ms_per_launch * 1e3,
+                               "algorithmic_bytes_per_env_step": bytes_per,
                                "algorithmic_bytes_per_launch": B * bytes_per}
-            out["value_without_dispatch_events"] = world * B * K / dt_plain if dt_plain else None
+            out["value_with_dispatch_events"] = world * B * K / dt_events
         if gather_ms is not None:
             out["ms_per_step_with_rccl_gather"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:

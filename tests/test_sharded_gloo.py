@@ -1,0 +1,96 @@
+"""N > 1 path on CPU: world_size-2 (and 3, ragged) gloo process groups exercise the env sharding, the action scatter and the
+packed (obs | reward | done | truncated) gather of space_gym_amd/sharded.py.  The per-rank engine is GPU-only, so the
+ranks drive the CPU oracle as a stand-in local engine (tests may use the oracle); the check is that the sharded run equals
+a single-process run of the full batch, env for env -- which also pins that the RNG is keyed by the GLOBAL env index."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+ENV_ID, NUM_ENVS, SEED, STEPS = "GoalContinuous3P-v0", 510, 17, 25
+
+
+class OracleLocalEngine:
+    """Stand-in for the GPU engine with the adapter interface ShardedVectorEnv expects."""
+
+    def __init__(self, env_id, n, seed, env_index_base, max_episode_steps):
+        from oracle import Oracle
+        self.o = Oracle(env_id)
+        self.o.params.max_episode_steps = max_episode_steps
+        self.n, self.seed, self.base, self.obs_dim = n, seed, env_index_base, self.o.obs_dim
+        self.envs = None
+
+    def reset_tensors(self):
+        self.envs, obs = self.o.vec_reset(self.n, seed=self.seed, env_id0=self.base)
+        return torch.from_numpy(obs.astype(np.float32))
+
+    def step_tensors(self, actions):
+        obs, rew, done, trunc = self.o.vec_step(self.envs, actions.numpy(), seed=self.seed, env_id0=self.base)
+        return (torch.from_numpy(obs.astype(np.float32)), torch.from_numpy(rew.astype(np.float32)),
+                torch.from_numpy(done), torch.from_numpy(trunc))
+
+    def close(self):
+        pass
+
+
+def _actions(t):
+    return np.random.default_rng(1000 + t).uniform(-1, 1, size=(NUM_ENVS, 2)).astype(np.float32)
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from space_gym_amd.sharded import ShardedVectorEnv, shard_bounds
+    lo, hi = shard_bounds(NUM_ENVS, world, rank)
+    eng = OracleLocalEngine(ENV_ID, hi - lo, SEED, lo, max_episode_steps=12)
+    env = ShardedVectorEnv(ENV_ID, NUM_ENVS, seed=SEED, local_env=eng, device="cpu")
+    assert (env.lo, env.hi) == (lo, hi)
+    trace = [env.reset()]
+    for t in range(STEPS):
+        trace.append(env.step(_actions(t) if rank == 0 else None))
+    if rank == 0:
+        np.savez(out_path, reset_obs=trace[0].numpy(), **{f"{k}{t}": v.numpy() for t, step in enumerate(trace[1:])
+                                                      for k, v in zip(("obs", "rew", "done", "trunc"), step)})
+    else:
+        assert all(x is None for x in trace)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single_process(world, tmp_path):
+    out = str(tmp_path / "rank0.npz")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = OracleLocalEngine(ENV_ID, NUM_ENVS, SEED, 0, max_episode_steps=12)
+    assert np.array_equal(got["reset_obs"], ref.reset_tensors().numpy())
+    n_done = 0
+    for t in range(STEPS):
+        obs, rew, done, trunc = (x.numpy() for x in ref.step_tensors(torch.from_numpy(_actions(t))))
+        assert np.array_equal(got[f"obs{t}"], obs) and np.array_equal(got[f"rew{t}"], rew)
+        assert np.array_equal(got[f"done{t}"], done) and np.array_equal(got[f"trunc{t}"], trunc)
+        n_done += int(done.sum())
+    assert n_done >= NUM_ENVS  # truncation at 12 steps: every env restarted at least once, on every rank
+
+
+def test_shard_bounds_partition():
+    from space_gym_amd.sharded import shard_bounds
+    for n, w in [(65536, 8), (524288, 8), (510, 3), (7, 8), (1, 1)]:
+        b = [shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
