@@ -5,9 +5,11 @@
     python bench.py --gpus 1 --steps 1000 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one launch of the fused step kernel over the whole per-GPU batch (integrate + events + observation +
-reward + goal resample + TimeLimit + auto-reset).  Inputs (a ring of U(-1,1) action blocks) are resident in HBM
-before the timed region; outputs go to a [steps, B, ...] rollout buffer in HBM.  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over the whole per-GPU batch (integrate + events + observation + reward + goal
+resample + TimeLimit + auto-reset for every env).  Inputs (U(-1,1) action blocks) are resident in HBM before the timed
+region; outputs go to a [steps, B, ...] rollout buffer in HBM.  The timed region is ONE sg_rollout_device call for the K
+steps: for the Goal ids that is one launch of the K-step rollout kernel (env state in registers across steps); the same K
+steps as K launches of the per-step kernel are timed too and reported beside it.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -85,7 +87,7 @@ def main():
     ap.add_argument("--env", default="GoalContinuous3P-v0")
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--action-ring", type=int, default=64, help="distinct pre-generated action blocks")
+    ap.add_argument("--action-ring", type=int, default=0, help="distinct pre-generated action blocks (0: one per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time a per-step RCCL gather of (obs,reward,done) to rank 0")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -114,7 +116,7 @@ def main():
     D = env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
-    ring = max(1, min(args.action_ring, max(K, W)))
+    ring = max(1, min(args.action_ring if args.action_ring > 0 else max(K, W), max(K, W)))
     actions = torch.rand((ring, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
     nbuf = max(K, W, 1)
     # rollout buffers in HBM (3.9 GB of observations at K=1000, B=65536, D=15)
@@ -149,6 +151,15 @@ def main():
 
     # ---- the same K steps again with start/stop events on every dispatch (hipExtLaunchKernelGGL): the kernel's own
     # duration, as rocprofv3 --kernel-trace reports it.  Costs ~35% throughput, hence not done in the region above.
+    # ---- A/B: the same K steps as K launches of the per-step kernel (what a policy-in-the-loop user gets)
+    env.set_unfused_rollout(True)
+    sync_all()
+    t_u = time.perf_counter()
+    env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+    sync_all()
+    dt_unfused = time.perf_counter() - t_u
+    env.set_unfused_rollout(False)
+
     launches, kern_ms, kmin, kmax, dt_events = 0, 0.0, 0.0, 0.0, None
     if timing:
         env.set_profiling(True)
@@ -188,26 +199,31 @@ def main():
             "ms_per_step": dt_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, batch={B} per GPU, i.i.d. U(-1,1) actions resident in HBM "
-                                   f"(ring of {ring} blocks), auto-reset on (termination or 500-step truncation), "
-                                   f"one fused step-kernel launch per step via sg_rollout_device, outputs to a "
-                                   f"[steps, B, ...] rollout buffer in HBM",
+                                   f"({ring} distinct blocks), auto-reset on (termination or 500-step truncation), "
+                                   f"the {K} steps in one sg_rollout_device call (Goal ids: one K-step kernel "
+                                   f"launch, env state in registers), outputs to a [steps, B, ...] rollout buffer in HBM",
                        "env_id": args.env, "batch_per_gpu": B, "global_batch": world * B, "obs_dim": D,
                        "parallelism": f"env-sharded x{world}, no data-path collective",
                        "episodes_finished_per_step": float(n_done.item()) / K},
         }
         if timing and launches:
             avg_us = kern_ms * 1e3 / launches
-            achieved = B * bytes_per / (avg_us * 1e-6) / 1e9
+            steps_per_launch = K // launches
+            achieved = steps_per_launch * B * bytes_per / (avg_us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.env, B),
-                               "kernel": "goal_step_kernel<3>" if args.env == "GoalContinuous3P-v0" else "step kernel",
+                               "kernel": ("goal_rollout_kernel<3>" if steps_per_launch > 1 else "goal_step_kernel<3>")
+                               if args.env == "GoalContinuous3P-v0" else "step kernel",
+                               "env_steps_per_launch": steps_per_launch * B,
                                "kernel_avg_us": avg_us, "kernel_min_us": kmin * 1e3, "kernel_max_us": kmax * 1e3,
                                "launches": launches, "timing": "hipExtLaunchKernelGGL start/stop events on each of the "
                                f"{launches} dispatches of a second, identical {K}-step pass",
                                "stream_event_us_per_launch_in_timed_region": stream_ms_per_launch * 1e3,
                                "algorithmic_bytes_per_env_step": bytes_per,
-                               "algorithmic_bytes_per_launch": B * bytes_per}
+                               "algorithmic_bytes_per_launch": steps_per_launch * B * bytes_per}
             out["value_with_dispatch_events"] = world * B * K / dt_events
+        out["value_one_launch_per_step"] = world * B * K / dt_unfused
+        out["ms_per_step_one_launch_per_step"] = dt_unfused * 1e3 / K
         if gather_ms is not None:
             out["ms_per_step_with_rccl_gather"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:

@@ -34,6 +34,7 @@ SYMBOLS = {
     "sg_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sg_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sg_rollout_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sg_set_unfused_rollout": (C.c_int, [_vp, C.c_int32]),
     "sg_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sg_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sg_set_profiling": (C.c_int, [_vp, C.c_int32]),

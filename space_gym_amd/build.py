@@ -22,7 +22,10 @@ def hipcc():
 
 
 def flags(extra=()):
-    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+    # -ffp-contract=on: a*b+c fuses per source expression, identically in every kernel that inlines the same device
+    # function (the default, fast, fuses across statements depending on context, so the per-step kernel and the fused
+    # rollout kernel would round differently)
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-ffp-contract=on",
             "-I", os.path.join(ROOT, "include"), "-I", CSRC, *extra]
 
 

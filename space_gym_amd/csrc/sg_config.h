@@ -50,6 +50,7 @@ typedef struct SgDev {
 
     /* HexagonalTiling, hexagonal_tiling.py:15-48,136-158 */
     int32_t t_rows, t_cols, t_tiles;
+    uint32_t t_cols_rcp16;      /* ceil(65536 / t_cols): tile / t_cols == (tile * rcp) >> 16 for tile < 64 (no runtime division) */
     float t_a, t_hex_h;
     float t_x0, t_y0;           /* centre of tile 0 before column shifts (case A) */
     float t_free_x;             /* world_size - tiling_width */

@@ -41,6 +41,10 @@
 #define SG_MFN inline
 #endif
 
+#ifndef SG_STAMP
+#define SG_STAMP(slot)
+#endif
+
 namespace sg {
 
 // ------------------------------------------------------------------------------------------------
@@ -171,6 +175,7 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
     float cqx[NC], cqy[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x0; cqy[k] = cay[k] - y0; }
+    SG_STAMP(8);
     float S0, C0;
     sincos_acc(th0, S0, C0);
     const float t_end = h_total;
@@ -206,6 +211,7 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
         h_abs = fminf(fminf(100.0f * h0, h1), t_end);
     }
 
+    SG_STAMP(9);
     // event functions at (t0, y0), ivp.py:646
     float g[NC + 2];
 #pragma unroll
@@ -410,6 +416,7 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
         }
 #pragma unroll
         for (int k = 0; k < NC + (WALLS ? 2 : 0); k++) g[k] = gn[k];
+        if (attempt == 0) { SG_STAMP(10); }
         t = t_new; X = Xn; Y = Yn; Xd = Xdn; Yd = Ydn; vx = vxn; vy = vyn;
 #pragma unroll
         for (int i = 0; i < 4; i++) k0[i] = k6[i];
@@ -572,6 +579,14 @@ SG_FN uint32_t free_total(uint64_t f) {
 }
 // tile at position `pos` of the sorted multiset (pos < total)
 SG_FN uint32_t free_at(uint64_t f, uint32_t pos) {
+    if ((f & 0xEEEEEEEEEEEEEEEEull) == 0) {  // every counter is 0 or 1: the (pos+1)-th set nibble
+        for (uint32_t j = 0; j < pos; j++) f &= f - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)(__ffsll((long long)f) - 1) >> 2;
+#else
+        return (uint32_t)__builtin_ctzll(f) >> 2;
+#endif
+    }
     uint32_t tile = 0, acc = 0;
 #pragma unroll
     for (uint32_t t = 0; t < 16; t++) {
@@ -589,7 +604,7 @@ SG_FN uint64_t free_remove(uint64_t f, uint32_t tile) { return f - (1ull << (4 *
 
 // hexagonal_tiling.py:136-158 _tile_center_pos
 SG_FN void tile_center(const SgDev &c, const Tiling &T, uint32_t tile, float &x, float &y) {
-    uint32_t row = tile / (uint32_t)c.t_cols, col = tile - row * (uint32_t)c.t_cols;
+    uint32_t row = (tile * c.t_cols_rcp16) >> 16, col = tile - row * (uint32_t)c.t_cols;
     const float shift = (col == 1u) ? T.cs1 : (col == 2u) ? T.cs2 : (col == 3u) ? T.cs3 : T.cs0;
     float tx = c.t_x0 + (float)col * 1.5f * c.t_a + shift;
     float y0 = T.case_b ? c.t_y0 - 0.5f * c.t_hex_h : c.t_y0;
@@ -619,7 +634,7 @@ SG_FN void choose_goal_tile(const SgDev &c, Tiling &T, bool first, const uint32_
         T.goal_tile = T.ship_tile;
     } else {
         const uint32_t n = free_total(T.free_counts), n_cand = n < 3u ? n : 3u;
-        const uint32_t cols = (uint32_t)c.t_cols, sr = T.ship_tile / cols, sc = T.ship_tile - sr * cols;
+        const uint32_t cols = (uint32_t)c.t_cols, sr = (T.ship_tile * c.t_cols_rcp16) >> 16, sc = T.ship_tile - sr * cols;
         const uint32_t draws[3] = {w[1] >> 16, w[1], w[2] >> 16};
         // choice(n, size=n_cand, replace=False) as a partial Fisher-Yates over positions 0..n-1 (slot i swaps with
         // slot j_i >= i).  With at most three draws the touched slots are tracked by value, not in an array:
@@ -643,7 +658,7 @@ SG_FN void choose_goal_tile(const SgDev &c, Tiling &T, bool first, const uint32_
         for (uint32_t i = 0; i < 3; i++) {  // fully unrolled: keeps chosen[] in registers
             if (i < n_cand) {
                 uint32_t tile = free_at(T.free_counts, chosen[i]);
-                uint32_t r = tile / cols, cc = tile - r * cols;
+                uint32_t r = (tile * c.t_cols_rcp16) >> 16, cc = tile - r * cols;
                 int dist = abs((int)r - (int)sr) + abs((int)cc - (int)sc);  // :119-121
                 if (dist > best_dist) { best_dist = dist; best_tile = tile; }  // first max, :122-124
             }
@@ -826,7 +841,9 @@ SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, floa
 #pragma unroll
     for (int j = 0; j < N; j++) { cR[j] = c.planet_r; cRd[j] = c.planet_r_d; }
     make_step<N, N, true>(c.h, c.half_world, c.gm, F, om, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd, r);
+    SG_STAMP(11);
     reward = goal_reward<N>(c, e.x, e.y, r.dXd, r.dYd, e.px, e.py, e.gx, e.gy, hit);
+    SG_STAMP(12);
     e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = om;
     e.th = wrap_two_pi(fmaf(om, r.t, e.th));
     done = r.done;

@@ -53,6 +53,7 @@ inline void fill_goal(SgDev &d, int n_planets) {
     d.danger_r2 = (planet_r + 0.25) * (planet_r + 0.25);  // goal.py:24
     d.survival = 0.2; d.goal_scale = 5.0 * 100.0; d.safety_scale = 10.0 * 100.0; d.sparse = 5.0;  // __init__.py:34-37, goal.py:16
     d.t_rows = rows; d.t_cols = cols; d.t_tiles = rows * cols;
+    d.t_cols_rcp16 = (65536u + (uint32_t)cols - 1u) / (uint32_t)cols;
     d.t_a = (float)a; d.t_hex_h = (float)hex_h;
     d.t_x0 = (float)(-world / 2 + a);          // hexagonal_tiling.py:145 (hex_width / 2 = a)
     d.t_y0 = (float)(world / 2 - hex_h / 2);   // :146
@@ -73,8 +74,13 @@ inline void fill_kepler(SgDev &d, double a, double ecc, double phi, int randomiz
     d.gm = (float)(G * 1.0 * 6e8);  // kepler.py:204
     d.planet_r = 0.2f; d.planet_r_d = 0.2; d.border_r = 3.0f;  // kepler.py:17-18
     d.k_a = a; d.k_ecc = ecc; d.k_phi = phi;
-    d.k_b = std::sqrt(a * a * (1 - ecc * ecc));
-    d.k_c = std::sqrt(a * a - d.k_b * d.k_b);
+    d.k_b = std::sqrt(a * a * (1 - ecc * ecc));   // kepler.py:43-45
+    // kepler.py:47-49.  Separate statements: with -ffp-contract=on a fused a*a - b*b can come out slightly negative for
+    // the circular orbit (the reference gets +2.2e-16 there, i.e. c = 1.5e-8).
+    const double aa = a * a;
+    const double bb = d.k_b * d.k_b;
+    const double c2 = aa - bb;
+    d.k_c = c2 > 0 ? std::sqrt(c2) : 0.0;
     d.k_cos = std::cos(phi); d.k_sin = std::sin(phi);
     d.k_gm = G * 6e8;
     d.k_C = 0.01; d.k_Cr = 2.0; d.k_Ca = 0.5f;  // gym_space/__init__.py:86-88

@@ -190,6 +190,10 @@ class SpaceGymVectorEnv:
         return obs, reward, done, trunc
 
 
+    def set_unfused_rollout(self, on):
+        """rollout_torch as K launches of the step kernel instead of the fused K-step kernel (A/B, equivalence test)."""
+        self._ck(self._lib.sg_set_unfused_rollout(self._h, int(bool(on))), "sg_set_unfused_rollout")
+
     # ------------------------------------------------------------------ measurement aid
     def set_profiling(self, on):
         self._ck(self._lib.sg_set_profiling(self._h, int(bool(on))), "sg_set_profiling")

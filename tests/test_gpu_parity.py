@@ -232,6 +232,43 @@ def test_device_tensor_path_matches_host_path():
     e1.close(); e2.close()
 
 
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0"])
+def test_fused_rollout_equals_step_by_step(env_id):
+    """sg_rollout_device (Goal: ONE launch for K steps, state in registers, restarts handed back through shuffles) is
+    bit-identical to K launches of the step kernel: outputs of every step and the final state, through several
+    generations of episodes and goal resamples."""
+    import torch
+    n, K = 8192, 300
+    a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1
+    outs = []
+    for unfused in (False, True):
+        env = make(env_id, n, seed=21, max_episode_steps=120)
+        env.set_unfused_rollout(unfused)
+        env.reset_torch()
+        D = env.obs_dim
+        obs = torch.empty((K, n, D), device="cuda"); rew = torch.empty((K, n), device="cuda")
+        done = torch.empty((K, n), dtype=torch.uint8, device="cuda"); trunc = torch.empty_like(done)
+        env.rollout_torch(a[:100], obs[:100], rew[:100], done[:100], trunc[:100])   # two calls: state survives between them
+        env.rollout_torch(a[100:], obs[100:], rew[100:], done[100:], trunc[100:])
+        torch.cuda.synchronize()
+        st = env.get_state()
+        outs.append((obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), trunc.cpu().numpy(), st))
+        env.close()
+    (o1, r1, d1, t1, s1), (o2, r2, d2, t2, s2) = outs
+    assert d1.sum() > 2 * n and t1.sum() > 0  # restarts by events and by truncation happened
+    for name, x, y in (("done", d1, d2), ("truncated", t1, t2), ("reward", r1, r2), ("obs", o1, o2)):
+        if not np.array_equal(x, y):
+            bad = np.argwhere(x != y)
+            t0 = bad[:, 0].min()
+            raise AssertionError(f"{name} differs first at step {t0}: {(bad[:, 0] == t0).sum()} entries; "
+                                 f"envs {bad[bad[:, 0] == t0][:5, 1]}, done there fused/unfused "
+                                 f"{d1[t0 - 1 if t0 else 0, bad[bad[:, 0] == t0][:5, 1]]}")
+    for k in ("ship", "goal", "elapsed"):
+        assert np.array_equal(s1[k], s2[k]), k
+    if s1["planets"] is not None:
+        assert np.array_equal(s1["planets"], s2["planets"])
+
+
 def test_sharding_is_invariant_to_the_split():
     """Two handles with env_index_base 0 and B/2 reproduce one handle of B envs bit for bit (RNG keyed by global index)."""
     n = 4096

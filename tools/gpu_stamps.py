@@ -14,7 +14,7 @@ import torch  # noqa: E402
 import space_gym_amd as sg  # noqa: E402
 from space_gym_amd import _native  # noqa: E402
 
-SLOTS, WAVES = 8, 8192
+SLOTS, WAVES = 16, 4096
 
 
 def read(lib):
@@ -26,6 +26,10 @@ def read(lib):
 def report(st, n_waves):
     st = st[:n_waves].astype(np.float64)
     d = {"loads (issue -> all back)": st[:, 1] - st[:, 0], "env_step (RK45 + events + reward + obs)": st[:, 2] - st[:, 1],
+         "  translate + sincos(theta0) .. initial-step rule done": st[:, 9] - st[:, 8],
+         "  initial-step rule -> end of 1st RK iteration (incl. its event check)": st[:, 10] - st[:, 9],
+         "  rest of the RK loop (2nd/3rd iterations, event roots)": st[:, 11] - st[:, 10],
+         "  reward (fp64)": st[:, 12] - st[:, 11], "  state update + observation": st[:, 2] - st[:, 12],
          "resample / restart branch": st[:, 3] - st[:, 2], "store issue": st[:, 4] - st[:, 3],
          "store drain": st[:, 5] - st[:, 4], "whole wave": st[:, 5] - st[:, 0]}
     real = (st[:, 7] - st[:, 6])

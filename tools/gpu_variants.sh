@@ -1,6 +1,6 @@
 #!/bin/bash
 # measurement aid: steady-state step-kernel time of differently compiled builds of the same library
-for v in "" _noslp _maxilp _noslp_maxilp; do
+for v in "" _maxilp _bias0 _maxilp_bias0; do
   lib=$GRAFT_REPO_ROOT/space_gym_amd/lib/libspacegym_hip$v.so
   [ -f $lib ] || continue
   echo "== $lib"
