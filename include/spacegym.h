@@ -80,8 +80,8 @@ int sg_step_device(sg_env *env, const float *actions_dev, float *obs_dev, float 
 
 /* `n_steps` consecutive steps for pre-supplied actions (open-loop rollout, e.g. random-action benchmarking or replaying an
  * action tape): actions [n_steps, num_envs, 2], obs [n_steps, num_envs, obs_dim], reward/done/truncated [n_steps, num_envs].
- * Bit-identical to n_steps calls of sg_step_device.  For the Goal ids all steps run in ONE kernel launch with the env state
- * held in registers; sg_set_unfused_rollout(env, 1) switches to n_steps launches of the step kernel. */
+ * Bit-identical to n_steps calls of sg_step_device.  All steps run in ONE kernel launch with the env state held in
+ * registers; sg_set_unfused_rollout(env, 1) switches to n_steps launches of the step kernel. */
 int sg_rollout_device(sg_env *env, int32_t n_steps, const float *actions_dev, float *obs_dev, float *reward_dev,
                       uint8_t *done_dev, uint8_t *truncated_dev, void *hip_stream);
 int sg_set_unfused_rollout(sg_env *env, int32_t on);

@@ -163,66 +163,87 @@ SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float
     }
 }
 
-// One env-step of dynamic_model.make_step (dynamic_model.py:94-125) in fp32.
+// dynamic_model.make_step (dynamic_model.py:94-125) in fp32, as a resumable integrator: begin() does what
+// RungeKutta.__init__ + the first event evaluation do, attempt() is one pass of RungeKutta._step_impl's loop body (one
+// accepted or rejected RK step) followed by solve_ivp's event handling.  make_step() below runs them to completion
+// (one launch per step); the rollout kernel calls attempt() once per loop iteration so that lanes whose env needs a
+// second RK step do not hold back the lanes that are done (sg_engine.hip).
 //   NC circles with radii cR (Goal: the planets; Kepler: planet + border, both centred on the origin),
 //   the first NG of them gravitate; WALLS adds the world_max / world_min events (dynamic_model.py:196-208).
 //   The angular-velocity event (:210-212, limit 6) cannot fire: |omega| = |5 a1| <= 5 for actions in [-1, 1].
-template <int NC, int NG, bool WALLS>
-SG_FN void make_step(float h_total, float half_world, float gm, float F, float om, float x0, float y0, float th0,
-                     float vx0, float vy0, const float (&cax)[NC], const float (&cay)[NC], const float (&cR)[NC],
-                     const double (&cRd)[NC], StepResult &o) {
-    // circle centres relative to the start position (fp32 working copy; the fp64 root polish uses cax/cay)
-    float cqx[NC], cqy[NC];
-#pragma unroll
-    for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x0; cqy[k] = cay[k] - y0; }
-    SG_STAMP(8);
-    float S0, C0;
-    sincos_acc(th0, S0, C0);
-    const float t_end = h_total;
-    float t = 0.0f, X = 0.0f, Y = 0.0f, vx = vx0, vy = vy0;
-    double Xd = 0.0, Yd = 0.0;
-    float k0[4], k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
+enum : int { kRkContinue = 0, kRkFinished = 1, kRkEvent = 2 };
 
-    // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
-    k0[0] = vx; k0[1] = vy;
-    accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
-    float h_abs;
-    {
-        // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega)
-        float sx = fmaf(fabsf(x0), kRtol, kAtol), sy = fmaf(fabsf(y0), kRtol, kAtol);
-        float sth = fmaf(fabsf(th0), kRtol, kAtol), som = fmaf(fabsf(om), kRtol, kAtol);
-        float svx = fmaf(fabsf(vx), kRtol, kAtol), svy = fmaf(fabsf(vy), kRtol, kAtol);
-        float isx = rcp(sx), isy = rcp(sy), isth = rcp(sth), isom = rcp(som), isvx = rcp(svx), isvy = rcp(svy);
-        float a0 = x0 * isx, a1 = y0 * isy, a2 = th0 * isth, a3 = vx * isvx, a4 = vy * isvy, a5 = om * isom;
-        float d0 = fsqrt((a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5) * (1.0f / 6));
-        // f0 = (vx, vy, omega, ax, ay, 0)
-        float b0 = vx * isx, b1 = vy * isy, b2 = om * isth, b3 = k0[2] * isvx, b4 = k0[3] * isvy;
-        float d1 = fsqrt((b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4) * (1.0f / 6));
-        float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);
-        h0 = fminf(h0, t_end);
-        // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)
-        float ax1, ay1;
-        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, h0, h0 * vx, h0 * vy, ax1, ay1);
-        float e0 = h0 * k0[2] * isx, e1 = h0 * k0[3] * isy, e3 = (ax1 - k0[2]) * isvx, e4 = (ay1 - k0[3]) * isvy;
-        float d2 = fsqrt((e0 * e0 + e1 * e1 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
-        float dm = fmaxf(d1, d2);
-        float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
-                                                   : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
-        h_abs = fminf(fminf(100.0f * h0, h1), t_end);
+template <int NC, int NG, bool WALLS>
+struct Integrator {
+    // constants of the env-step
+    float t_end, half_world, gm, F, om, x0, y0, C0, S0;
+    float cax[NC], cay[NC], cR[NC], cqx[NC], cqy[NC];
+    double cRd[NC];
+    float wxp, wyp, wxm, wym;
+    // running state
+    float t, X, Y, vx, vy, h_abs;
+    double Xd, Yd;
+    float k0[4], g[NC + 2];
+    bool rejected;
+    int n_rk, attempts;
+
+    SG_MFN void begin(float h_total, float half_world_, float gm_, float F_, float om_, float x0_, float y0_, float th0,
+                      float vx0, float vy0, const float (&cax_)[NC], const float (&cay_)[NC], const float (&cR_)[NC],
+                      const double (&cRd_)[NC]) {
+        SG_STAMP(8);
+        half_world = half_world_; gm = gm_; F = F_; om = om_; x0 = x0_; y0 = y0_;
+#pragma unroll
+        for (int k = 0; k < NC; k++) { cax[k] = cax_[k]; cay[k] = cay_[k]; cR[k] = cR_[k]; cRd[k] = cRd_[k]; }
+        sincos_acc(th0, S0, C0);
+        t_end = h_total;
+        t = 0.0f; X = 0.0f; Y = 0.0f; vx = vx0; vy = vy0;
+        Xd = 0.0; Yd = 0.0;
+        // circle centres relative to the start position (fp32 working copy; the fp64 root polish uses cax/cay)
+    #pragma unroll
+        for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x0; cqy[k] = cay[k] - y0; }
+
+        // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
+        k0[0] = vx; k0[1] = vy;
+        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
+        {
+            // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega)
+            float sx = fmaf(fabsf(x0), kRtol, kAtol), sy = fmaf(fabsf(y0), kRtol, kAtol);
+            float sth = fmaf(fabsf(th0), kRtol, kAtol), som = fmaf(fabsf(om), kRtol, kAtol);
+            float svx = fmaf(fabsf(vx), kRtol, kAtol), svy = fmaf(fabsf(vy), kRtol, kAtol);
+            float isx = rcp(sx), isy = rcp(sy), isth = rcp(sth), isom = rcp(som), isvx = rcp(svx), isvy = rcp(svy);
+            float a0 = x0 * isx, a1 = y0 * isy, a2 = th0 * isth, a3 = vx * isvx, a4 = vy * isvy, a5 = om * isom;
+            float d0 = fsqrt((a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5) * (1.0f / 6));
+            // f0 = (vx, vy, omega, ax, ay, 0)
+            float b0 = vx * isx, b1 = vy * isy, b2 = om * isth, b3 = k0[2] * isvx, b4 = k0[3] * isvy;
+            float d1 = fsqrt((b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4) * (1.0f / 6));
+            float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);
+            h0 = fminf(h0, t_end);
+            // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)
+            float ax1, ay1;
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, h0, h0 * vx, h0 * vy, ax1, ay1);
+            float e0 = h0 * k0[2] * isx, e1 = h0 * k0[3] * isy, e3 = (ax1 - k0[2]) * isvx, e4 = (ay1 - k0[3]) * isvy;
+            float d2 = fsqrt((e0 * e0 + e1 * e1 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
+            float dm = fmaxf(d1, d2);
+            float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
+                                                       : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
+            h_abs = fminf(fminf(100.0f * h0, h1), t_end);
+        }
+
+        SG_STAMP(9);
+        // event functions at (t0, y0), ivp.py:646
+    #pragma unroll
+        for (int k = 0; k < NC; k++) g[k] = fsqrt(fmaf(cqx[k], cqx[k], cqy[k] * cqy[k])) - cR[k];
+        wxp = half_world - x0; wyp = half_world - y0; wxm = half_world + x0; wym = half_world + y0;
+        if (WALLS) { g[NC] = fminf(wxp, wyp); g[NC + 1] = fminf(wxm, wym); }
+
+        rejected = false; n_rk = 0; attempts = 0;
     }
 
-    SG_STAMP(9);
-    // event functions at (t0, y0), ivp.py:646
-    float g[NC + 2];
-#pragma unroll
-    for (int k = 0; k < NC; k++) g[k] = fsqrt(fmaf(cqx[k], cqx[k], cqy[k] * cqy[k])) - cR[k];
-    const float wxp = half_world - x0, wyp = half_world - y0, wxm = half_world + x0, wym = half_world + y0;
-    if (WALLS) { g[NC] = fminf(wxp, wyp); g[NC + 1] = fminf(wxm, wym); }
-
-    o.done = 0; o.event = -1; o.n_rk = 0;
-    bool rejected = false;
-    for (int attempt = 0; attempt < kMaxRkAttempts; attempt++) {
-        if (!(t < t_end)) break;
+    // One RK attempt.  Returns kRkContinue, or fills `o` and returns kRkFinished / kRkEvent.
+    SG_MFN int attempt(StepResult &o) {
+        attempts++;
+        if (!(t < t_end) || attempts > kMaxRkAttempts) { finish(o); return kRkFinished; }
+        float k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
         // RungeKutta._step_impl (rk.py:111-176)
         h_abs = fmaxf(h_abs, 1e-9f);
         float t_new = t + h_abs;
@@ -292,13 +313,13 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
         if (!(err < 1.0f)) {  // rejected (also for NaN): shrink and retry
             h_abs = h * fmaxf(kMinFactor, kSafety * fexp2(-0.2f * flog2(err)));
             rejected = true;
-            continue;
+            return kRkContinue;
         }
         float factor = (err == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * fexp2(-0.2f * flog2(err)));
         if (rejected) factor = fminf(1.0f, factor);
         rejected = false;
         h_abs = h * factor;
-        o.n_rk++;
+        n_rk++;
 
         // events over this accepted step (ivp.py:673-694, find_active_events with direction 0)
         float gn[NC + 2];
@@ -411,17 +432,32 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
             o.dX = (float)o.dXd; o.dY = (float)o.dYd;
             o.vx = vx + disp(2, s); o.vy = vy + disp(3, s);
             o.t = fmaf(h, s, t);
-            o.done = 1; o.event = best_k;
-            return;
+            o.done = 1; o.event = best_k; o.n_rk = n_rk;
+            return kRkEvent;
         }
 #pragma unroll
         for (int k = 0; k < NC + (WALLS ? 2 : 0); k++) g[k] = gn[k];
-        if (attempt == 0) { SG_STAMP(10); }
+        if (attempts == 1) { SG_STAMP(10); }
         t = t_new; X = Xn; Y = Yn; Xd = Xdn; Yd = Ydn; vx = vxn; vy = vyn;
 #pragma unroll
         for (int i = 0; i < 4; i++) k0[i] = k6[i];
+        if (!(t < t_end)) { finish(o); return kRkFinished; }
+        return kRkContinue;
     }
-    o.dXd = Xd; o.dYd = Yd; o.dX = X; o.dY = Y; o.vx = vx; o.vy = vy; o.t = t;
+
+    SG_MFN void finish(StepResult &o) const {
+        o.dXd = Xd; o.dYd = Yd; o.dX = X; o.dY = Y; o.vx = vx; o.vy = vy; o.t = t;
+        o.done = 0; o.event = -1; o.n_rk = n_rk;
+    }
+};
+
+template <int NC, int NG, bool WALLS>
+SG_FN void make_step(float h_total, float half_world, float gm, float F, float om, float x0, float y0, float th0,
+                     float vx0, float vy0, const float (&cax)[NC], const float (&cay)[NC], const float (&cR)[NC],
+                     const double (&cRd)[NC], StepResult &o) {
+    Integrator<NC, NG, WALLS> I;
+    I.begin(h_total, half_world, gm, F, om, x0, y0, th0, vx0, vy0, cax, cay, cR, cRd);
+    while (I.attempt(o) == kRkContinue) {}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,17 +866,22 @@ SG_FN void kepler_observe(const SgDev &c, const KeplerEnv &e, float (&obs)[10]) 
     obs[9] = (float)c.k_a;
 }
 
-// Goal: integrate -> observation (old goal) -> reward; the caller resamples the goal on a hit (goal.py:154-157)
+// Goal: integrate -> observation (old goal) -> reward; the caller resamples the goal on a hit (goal.py:154-157).
+// Split into begin / finish around the resumable integrator so that the rollout kernel can interleave envs.
 template <int N>
-SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, float (&obs)[7 + 2 * N + 2], float &reward,
-                         int &done, int &hit, StepResult &r) {
+SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true> &I) {
     float engine, F, om;
     translate_action(a0, a1, c.max_engine_force, engine, F, om);
     float cR[N];
     double cRd[N];
 #pragma unroll
     for (int j = 0; j < N; j++) { cR[j] = c.planet_r; cRd[j] = c.planet_r_d; }
-    make_step<N, N, true>(c.h, c.half_world, c.gm, F, om, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd, r);
+    I.begin(c.h, c.half_world, c.gm, F, om, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd);
+}
+
+template <int N>
+SG_FN void goal_env_finish(const SgDev &c, GoalEnv<N> &e, float om, const StepResult &r, float (&obs)[7 + 2 * N + 2],
+                           float &reward, int &done, int &hit) {
     SG_STAMP(11);
     reward = goal_reward<N>(c, e.x, e.y, r.dXd, r.dYd, e.px, e.py, e.gx, e.gy, hit);
     SG_STAMP(12);
@@ -848,6 +889,15 @@ SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, floa
     e.th = wrap_two_pi(fmaf(om, r.t, e.th));
     done = r.done;
     goal_observe<N>(c, e, obs);
+}
+
+template <int N>
+SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, float (&obs)[7 + 2 * N + 2], float &reward,
+                         int &done, int &hit, StepResult &r) {
+    Integrator<N, N, true> I;
+    goal_env_begin<N>(c, e, a0, a1, I);
+    while (I.attempt(r) == kRkContinue) {}
+    goal_env_finish<N>(c, e, I.om, r, obs, reward, done, hit);
 }
 
 SG_FN Orbit fixed_orbit(const SgDev &c) {

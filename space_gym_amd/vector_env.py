@@ -192,7 +192,7 @@ class SpaceGymVectorEnv:
 
     def set_unfused_rollout(self, on):
         """rollout_torch as K launches of the step kernel instead of the fused K-step kernel (A/B, equivalence test)."""
-        self._ck(self._lib.sg_set_unfused_rollout(self._h, int(bool(on))), "sg_set_unfused_rollout")
+        self._ck(self._lib.sg_set_unfused_rollout(self._h, int(on)), "sg_set_unfused_rollout")
 
     # ------------------------------------------------------------------ measurement aid
     def set_profiling(self, on):

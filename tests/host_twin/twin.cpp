@@ -1,6 +1,7 @@
 // Host twin of the device math (TEST-ONLY): space_gym_amd/csrc/sg_device.hpp compiled by g++ so the fp32
 // numerics of the engine can be checked against the oracle and the golden vectors without a GPU.
 // It is built by tests/host_twin/build.py into tests/host_twin/_build and is never loaded by the product.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 
@@ -38,6 +39,7 @@ extern "C" int twin_obs_dim(const char *env_id) {
     return obs_dim(c);
 }
 
+// Kepler: `goal` may carry a per-env orbit (phi, ecc) as for KeplerRandomOrbits-v0 (the engine stores cos/sin phi in fp64)
 extern "C" int twin_step(const char *env_id, int64_t m, const float *state, const float *planets, const float *goal,
                          const float *action, float *state1, float *obs, float *reward, uint8_t *done, uint8_t *hit,
                          float *t_adv, int32_t *n_rk, int32_t *event) {
@@ -49,12 +51,17 @@ extern "C" int twin_step(const char *env_id, int64_t m, const float *state, cons
         else goal_steps<4>(c, m, state, planets, goal, action, state1, obs, reward, done, hit, t_adv, n_rk, event);
         return 0;
     }
-    const Orbit ob = fixed_orbit(c);
     for (int64_t i = 0; i < m; i++) {
         KeplerEnv e;
         const float *s = state + 6 * i;
         e.x = s[0]; e.y = s[1]; e.th = s[2]; e.vx = s[3]; e.vy = s[4]; e.om = s[5];
         e.phi = (float)c.k_phi; e.ecc = (float)c.k_ecc;
+        Orbit ob = fixed_orbit(c);
+        if (goal) {
+            c.randomize_orbit = 1;
+            e.phi = goal[2 * i]; e.ecc = goal[2 * i + 1];
+            ob = make_orbit(c.k_a, (double)e.ecc, std::cos((double)e.phi), std::sin((double)e.phi));
+        }
         float o[10], r;
         int dn;
         StepResult sr;

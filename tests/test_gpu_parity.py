@@ -64,7 +64,7 @@ def test_step_matches_reference_golden(fam, golden_steps):
 
 @pytest.mark.parametrize("env_id,n", [("GoalContinuous2P-v0", 4096), ("GoalContinuous3P-v0", 65536),
                                       ("KeplerCircleOrbit-v0", 65536), ("GoalContinuous4P-v0", 65536),
-                                      ("KeplerEllipseHard-v0", 8192)])
+                                      ("KeplerEllipseHard-v0", 8192), ("KeplerRandomOrbits-v0", 16384)])
 def test_rollout_steps_match_oracle(env_id, n):
     """BASELINE.json configs at full batch: engine-generated states (own reset + auto-reset rollout), every step
     re-checked against the oracle applied to the engine's own pre-step state."""
@@ -81,8 +81,11 @@ def test_rollout_steps_match_oracle(env_id, n):
         a = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
         obs, rew, done, info = env.step(a)
         s1 = env.get_state()
+        orbit = None
+        if "Random" in env_id:  # per-env (angle, eccentricity); a = 1.2 for every id
+            orbit = np.concatenate([st["goal"].astype(np.float64), np.full((n, 1), 1.2)], axis=1)
         ref = o.step(st["ship"].astype(np.float64), a, st["planets"].astype(np.float64) if is_goal else None,
-                     st["goal"].astype(np.float64) if is_goal else None)
+                     st["goal"].astype(np.float64) if is_goal else None, orbit=orbit)
         trunc = info["TimeLimit.truncated"]
         ref_done = ref["done"].astype(bool) | trunc
         # finished envs were restarted inside the kernel: their last observation is in info["terminal_observation"],
@@ -165,7 +168,8 @@ def test_time_limit_and_auto_reset():
     env.close()
 
 
-@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0"])
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0",
+                                    "KeplerRandomOrbits-v0"])
 def test_reset_matches_oracle_sampler(env_id):
     """Same counter-based RNG words on both sides: tile decisions are integer-exact, positions agree to fp32."""
     n = 8192
@@ -180,6 +184,8 @@ def test_reset_matches_oracle_sampler(env_id):
         N = st["planets"].shape[1]
         assert np.abs(st["planets"] - envs["planets_xy"][:, :N]).max() < 2e-6
         assert np.abs(st["goal"] - envs["goal_xy"]).max() < 2e-6
+    elif "Random" in env_id:
+        assert np.abs(st["goal"] - envs["orbit"][:, :2]).max() < 2e-6  # (orbit angle, eccentricity) per env
     env.close()
 
 
@@ -232,7 +238,8 @@ def test_device_tensor_path_matches_host_path():
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0"])
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0",
+                                    "KeplerRandomOrbits-v0"])
 def test_fused_rollout_equals_step_by_step(env_id):
     """sg_rollout_device (Goal: ONE launch for K steps, state in registers, restarts handed back through shuffles) is
     bit-identical to K launches of the step kernel: outputs of every step and the final state, through several
@@ -241,9 +248,9 @@ def test_fused_rollout_equals_step_by_step(env_id):
     n, K = 8192, 300
     a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1
     outs = []
-    for unfused in (False, True):
+    for mode in (0, 1):  # one K-step launch (default) | one launch per step
         env = make(env_id, n, seed=21, max_episode_steps=120)
-        env.set_unfused_rollout(unfused)
+        env.set_unfused_rollout(mode)
         env.reset_torch()
         D = env.obs_dim
         obs = torch.empty((K, n, D), device="cuda"); rew = torch.empty((K, n), device="cuda")
@@ -255,6 +262,10 @@ def test_fused_rollout_equals_step_by_step(env_id):
         outs.append((obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), trunc.cpu().numpy(), st))
         env.close()
     (o1, r1, d1, t1, s1), (o2, r2, d2, t2, s2) = outs
+    _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2)
+
+
+def _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2):
     assert d1.sum() > 2 * n and t1.sum() > 0  # restarts by events and by truncation happened
     for name, x, y in (("done", d1, d2), ("truncated", t1, t2), ("reward", r1, r2), ("obs", o1, o2)):
         if not np.array_equal(x, y):

@@ -162,3 +162,24 @@ def test_kepler_reset_distribution_matches_reference():
         ok, info = chi2_ok(mine, theirs)
         assert ok, (name, info)
     assert abs(s[:, 3:5].std() - ref["vel_std"]) < 1e-3 and abs(s[:, 5].std() - ref["omega_std"]) < 0.01
+
+
+def test_random_orbits_step_matches_oracle():
+    """KeplerRandomOrbits-v0 (kepler.py:257-259): per-env (angle, eccentricity) in the reward and the observation tail."""
+    rng = np.random.default_rng(8)
+    n = 6000
+    o, t = Oracle("KeplerRandomOrbits-v0"), Twin("KeplerRandomOrbits-v0")
+    envs, _ = o.vec_reset(n, seed=5)
+    for _ in range(25):
+        o.vec_step(envs, rng.uniform(-1, 1, size=(n, 2)).astype(np.float32), seed=5)
+    s0 = envs["state"].astype(np.float32)
+    orbit = envs["orbit"].astype(np.float32)  # (angle, ecc, a)
+    assert orbit[:, 1].max() < 0.7 and orbit[:, 1].std() > 0.1
+    a = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+    a[: n // 4] = [-1.0, 0.0]  # engine off: rewards close to 1 are the sensitive regime
+    ref = o.step(s0.astype(np.float64), a, orbit=orbit.astype(np.float64))
+    tw = t.step(s0, a, goal=orbit[:, :2].copy())
+    assert np.array_equal(tw["done"], ref["done"])
+    assert np.abs(tw["state1"][:, [0, 1, 3, 4, 5]] - ref["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
+    assert np.abs(tw["obs"] - ref["obs"]).max() <= TOL_OBS
+    assert (np.abs(tw["reward"] - ref["reward"]) / np.maximum(1, np.abs(ref["reward"]))).max() <= TOL_REWARD_REL
