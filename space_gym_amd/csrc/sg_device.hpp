@@ -12,7 +12,7 @@
  *                    also where RK45's own truncation error is visible (fast grazes near a planet).
  *   - events         dynamic_model.py:183-217 with scipy's sign-change detection per accepted RK
  *                    step (ivp.py:133-156) and a root on the same 4th-order dense output
- *                    (rk.py RkDenseOutput) -- located with a bracketed Illinois iteration.
+ *                    (rk.py RkDenseOutput) -- located with a bracketed Newton iteration.
  *   - observation    gym_space/envs/spaceship_env.py:113-140, kepler.py:172-187
  *   - rewards        goal.py:147-158,160-164,204-227; kepler.py:43-156 (fp64 epilogue)
  *   - reset sampler  hexagonal_tiling.py:53-158, goal.py:133-145, kepler.py:233-267 on a counter-based
@@ -129,7 +129,8 @@ constexpr float P71 = (float)(40617522.0 / 29380423.0), P72 = (float)(-110615467
 constexpr float kRtol = 1e-3f, kAtol = 1e-6f;  // solve_ivp defaults (dynamic_model.py:112-118 passes none)
 constexpr float kSafety = 0.9f, kMinFactor = 0.2f, kMaxFactor = 10.0f;  // rk.py:8-11
 constexpr int kMaxRkAttempts = 12;  // bound on accepted+rejected RK steps per env-step (reference mean: 1.19)
-constexpr int kRootIters = 6;   // fp32 Illinois iterations before the fp64 Newton polish
+constexpr int kRootIters = 2;      // minimum fp32 safeguarded-Newton iterations before the fp64 Newton polish ...
+constexpr int kRootMaxIters = 28;  // ... and the cap for lanes that have not settled by then (near-tangent grazes)
 
 struct StepResult {
     double dXd, dYd; // displacement from the start position, fp64 accumulation of h v + h^2 sum_l beta_l a_l
@@ -372,36 +373,56 @@ struct Integrator {
                 const bool circle = k < NC, leaving = g0 > 0.0f;
                 const float sgn = (k == NC) ? 1.0f : -1.0f;                      // world_max : world_min
                 const float wx = (k == NC) ? wxp : wxm, wy = (k == NC) ? wyp : wym;
-                float root = leaving ? 2.0f : -1.0f;
-                int root_comp = 0;
-                for (int comp = 0; comp < (WALLS ? 2 : 1); comp++) {
-                    if (circle && comp == 1) continue;
-                    float ga, gb;
-                    if (circle) { ga = g0; gb = g1; }
-                    else {
-                        ga = comp ? wy - sgn * Y : wx - sgn * X;
-                        gb = comp ? wy - sgn * Yn : wx - sgn * Xn;
-                        if (!((ga <= 0.0f && gb >= 0.0f) || (ga >= 0.0f && gb <= 0.0f))) continue;  // this part does not cross
+                // Two slots solved side by side (independent chains -> ILP for the lone wave):
+                //   slot A: the circle, or the x part of a wall event;   slot B: the y part of a wall event.
+                // Safeguarded Newton from the regula-falsi point; the parts are nearly linear in s over one RK step.
+                float gaA, gbA, gaB = 1.0f, gbB = 1.0f;
+                if (circle) { gaA = g0; gbA = g1; }
+                else { gaA = wx - sgn * X; gbA = wx - sgn * Xn; gaB = wy - sgn * Y; gbB = wy - sgn * Yn; }
+                const bool crossA = (gaA <= 0.0f && gbA >= 0.0f) || (gaA >= 0.0f && gbA <= 0.0f);
+                const bool crossB = !circle && ((gaB <= 0.0f && gbB >= 0.0f) || (gaB >= 0.0f && gbB <= 0.0f));
+                float loA = 0.0f, hiA = 1.0f, loB = 0.0f, hiB = 1.0f;
+                float denA = gaA - gbA, denB = gaB - gbB;
+                float sA = (denA != 0.0f) ? fminf(fmaxf(gaA * rcp(denA), 0.0f), 1.0f) : 0.0f;
+                float sB = (denB != 0.0f) ? fminf(fmaxf(gaB * rcp(denB), 0.0f), 1.0f) : 0.0f;
+                for (int it = 0; it < kRootMaxIters; it++) {
+                    const float pA = sA, pB = sB;
+                    if (crossA) {  // slot A: circle or x part (branches are skipped wave-wide when no lane needs them)
+                        float gA, gpA;
+                        const float dxA = X + disp(0, sA), uxA = dispd(0, sA);
+                        if (circle) {
+                            const float dyA = Y + disp(1, sA), uyA = dispd(1, sA);
+                            const float exA = ecx - dxA, eyA = ecy - dyA;
+                            const float r2A = fmaf(exA, exA, eyA * eyA), irA = rsq(r2A);
+                            gA = r2A * irA - eR;
+                            gpA = -(exA * uxA + eyA * uyA) * irA;
+                        } else {
+                            gA = wx - sgn * dxA;
+                            gpA = -sgn * uxA;
+                        }
+                        if ((gA > 0.0f) == (gaA > 0.0f)) loA = sA; else hiA = sA;   // g(lo) keeps the sign of g(0)
+                        const float nA = sA - gA * rcp(gpA);
+                        sA = (nA > loA && nA < hiA) ? nA : ((gA == 0.0f) ? sA : 0.5f * (loA + hiA));
                     }
-                    auto gfun = [&](float s) __attribute__((always_inline)) {
-                        float dx = X + disp(0, s), dy = Y + disp(1, s);
-                        float ex = ecx - dx, ey = ecy - dy;
-                        float gc = fsqrt(fmaf(ex, ex, ey * ey)) - eR;
-                        float gw = comp ? wy - sgn * dy : wx - sgn * dx;
-                        return circle ? gc : gw;
-                    };
-                    // Illinois (modified regula falsi) on the bracket [0, 1]
-                    float a = 0.0f, b = 1.0f;
-                    for (int it = 0; it < kRootIters; it++) {
-                        float den = gb - ga;
-                        float c = (den == 0.0f) ? b : b - gb * (b - a) * rcp(den);
-                        c = fminf(fmaxf(c, 0.0f), 1.0f);
-                        float gc = gfun(c);
-                        if (gc * gb < 0.0f) { a = b; ga = gb; } else { ga *= 0.5f; }
-                        b = c; gb = gc;
+                    if (crossB) {  // slot B: y part of a wall event
+                        const float dyB = Y + disp(1, sB), uyB = dispd(1, sB);
+                        const float gB = wy - sgn * dyB, gpB = -sgn * uyB;
+                        if ((gB > 0.0f) == (gaB > 0.0f)) loB = sB; else hiB = sB;
+                        const float nB = sB - gB * rcp(gpB);
+                        sB = (nB > loB && nB < hiB) ? nB : ((gB == 0.0f) ? sB : 0.5f * (loB + hiB));
                     }
-                    if (leaving ? (b < root) : (b > root)) { root = b; root_comp = comp; }
+                    // well-conditioned roots settle in 2-3 passes; near-tangent grazes (slope ~ 0) keep going, bisecting
+                    const bool convA = !crossA || fabsf(sA - pA) <= 1e-6f, convB = !crossB || fabsf(sB - pB) <= 1e-6f;
+                    if (it >= kRootIters - 1 && convA && convB) break;
                 }
+                // the event function is the circle, or min(x part, y part): leaving the world the first part to cross
+                // wins, entering it (injected states only) the last one does
+                float root;
+                int root_comp = 0;
+                if (circle) root = sA;
+                else if (crossA && crossB) { const bool pickB = leaving ? (sB < sA) : (sB > sA); root = pickB ? sB : sA; root_comp = pickB; }
+                else if (crossB) { root = sB; root_comp = 1; }
+                else root = crossA ? sA : (leaving ? 2.0f : -1.0f);
                 if (root < best && root >= 0.0f) { best = root; best_k = k; best_comp = root_comp; bax = eax; bay = eay; bRd = eRd; }
             }
             // One Newton step on the winning component with g evaluated in fp64 from the unrounded inputs: the Goal

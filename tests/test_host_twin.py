@@ -183,3 +183,52 @@ def test_random_orbits_step_matches_oracle():
     assert np.abs(tw["state1"][:, [0, 1, 3, 4, 5]] - ref["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
     assert np.abs(tw["obs"] - ref["obs"]).max() <= TOL_OBS
     assert (np.abs(tw["reward"] - ref["reward"]) / np.maximum(1, np.abs(ref["reward"]))).max() <= TOL_REWARD_REL
+
+
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "KeplerEllipseHard-v0"])
+def test_event_roots_on_grazing_and_corner_cases(env_id):
+    """Adversarial terminal steps against the oracle: ships 0.2 mm..7 cm from a planet / the border circle / a wall / a
+    corner, heading within 87 degrees of the normal at up to 2.5 units/s (near-tangent grazes have ill-conditioned roots;
+    the wall events min(W/2 -+ x, W/2 -+ y) have a kink at corners)."""
+    rng = np.random.default_rng(3)
+    o, t = Oracle(env_id, threads=4), Twin(env_id)
+    n = 60000
+
+    def unit(a):
+        return np.stack([np.cos(a), np.sin(a)], -1)
+    envs, _ = o.vec_reset(n, seed=1)
+    P = g = None
+    if o.is_goal:
+        N, R = o.n_planets, o.params.planet_radius[0]
+        P, g = envs["planets_xy"][:, :N].astype(np.float32), envs["goal_xy"].astype(np.float32)
+        j, ang = rng.integers(0, N, n), rng.uniform(0, 2 * np.pi, n)
+        pos = P[np.arange(n), j] + unit(ang) * (R + rng.uniform(0.0002, 0.07, n))[:, None]
+        vel = -unit(ang + np.deg2rad(rng.uniform(-87, 87, n))) * rng.uniform(0.05, 2.5, n)[:, None]
+        w = rng.uniform(size=n) < 0.4  # walls and corners
+        k = int(w.sum())
+        posw = rng.uniform(-1.45, 1.45, (k, 2)); ax = rng.integers(0, 2, k); sg = rng.choice([-1., 1.], k)
+        posw[np.arange(k), ax] = sg * (1.5 - rng.uniform(0, 0.06, k))
+        cor = rng.uniform(size=k) < 0.3
+        posw[cor, 1 - ax[cor]] = rng.choice([-1., 1.], int(cor.sum())) * (1.5 - rng.uniform(0, 0.06, int(cor.sum())))
+        velw = rng.normal(size=(k, 2)) * 0.7; velw[np.arange(k), ax] = sg * rng.uniform(0.05, 2.0, k)
+        pos[w], vel[w] = posw, velw
+        ok = np.all(np.abs(pos) < 1.5, axis=1) & (np.linalg.norm(P - pos[:, None], axis=2).min(1) > R)
+    else:
+        inner, ang = rng.uniform(size=n) < 0.5, rng.uniform(0, 2 * np.pi, n)
+        rad = np.where(inner, 0.2 + rng.uniform(0.0002, 0.07, n), 3.0 - rng.uniform(0.0002, 0.07, n))
+        pos = unit(ang) * rad[:, None]
+        vel = np.where(inner, -1.0, 1.0)[:, None] * unit(ang + np.deg2rad(rng.uniform(-87, 87, n))) * rng.uniform(0.05, 2.5, n)[:, None]
+        ok = np.ones(n, bool)
+    s0 = np.concatenate([pos, rng.uniform(0, 2 * np.pi, (n, 1)), vel, rng.normal(size=(n, 1))], 1).astype(np.float32)[ok]
+    a = rng.uniform(-1, 1, (len(s0), 2)).astype(np.float32)
+    Pk, gk = (P[ok], g[ok]) if P is not None else (None, None)
+    ref = o.step(s0.astype(np.float64), a, None if Pk is None else Pk.astype(np.float64),
+                 None if gk is None else gk.astype(np.float64), with_diag=True)
+    tw = t.step(s0, a, Pk, gk)
+    term = ref["done"] == 1
+    assert term.mean() > 0.4
+    assert np.array_equal(tw["done"], ref["done"]) and np.array_equal(tw["event"][term], ref["diag"]["event_index"][term])
+    assert np.abs(tw["t"][term] - ref["diag"]["t_event"][term]).max() < 1e-6
+    assert np.abs(tw["state1"][:, [0, 1, 3, 4, 5]] - ref["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
+    assert np.abs(tw["obs"] - ref["obs"]).max() <= TOL_OBS
+    assert (np.abs(tw["reward"] - ref["reward"]) / np.maximum(1, np.abs(ref["reward"]))).max() <= TOL_REWARD_REL

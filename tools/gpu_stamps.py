@@ -30,10 +30,19 @@ def report(st, n_waves):
          "  initial-step rule -> end of 1st RK iteration (incl. its event check)": st[:, 10] - st[:, 9],
          "  rest of the RK loop (2nd/3rd iterations, event roots)": st[:, 11] - st[:, 10],
          "  reward (fp64)": st[:, 12] - st[:, 11], "  state update + observation": st[:, 2] - st[:, 12],
-         "resample / restart branch": st[:, 3] - st[:, 2], "store issue": st[:, 4] - st[:, 3],
+         "owner stores": st[:, 3] - st[:, 2], "service (ballot .. restarts/resamples done)": st[:, 4] - st[:, 3],
+         "  [waves with a restart] entry -> Philox + word exchange": st[:, 13] - st[:, 3],
+         "  [..] layout + tiles + goal tile": st[:, 14] - st[:, 13],
+         "  [..] disc samples + Box-Muller + exchange": st[:, 15] - st[:, 14],
+         "  [..] column/obs stores -> end of service": st[:, 4] - st[:, 15],
          "store drain": st[:, 5] - st[:, 4], "whole wave": st[:, 5] - st[:, 0]}
     real = (st[:, 7] - st[:, 6])
-    out = {k: dict(mean=float(v.mean()), p50=float(np.median(v)), p95=float(np.percentile(v, 95)), max=float(v.max())) for k, v in d.items()}
+    had_restart = st[:, 13] > st[:, 3]  # slots 13..15 are only written (this launch) by waves that restarted an env
+    out = {}
+    for k, v in d.items():
+        if k.startswith("  [") and had_restart.any():
+            v = v[had_restart]
+        out[k] = dict(mean=float(v.mean()), p50=float(np.median(v)), p95=float(np.percentile(v, 95)), max=float(v.max()), n=int(v.size))
     out["clock_GHz (cycles / 100MHz ticks)"] = float((st[:, 5] - st[:, 0]).sum() / (real.sum() * 10.0))
     out["kernel span: first wave start -> last wave end (us, 100 MHz clock)"] = float((st[:, 7].max() - st[:, 6].min()) / 100.0)
     out["wave start skew (us)"] = float((st[:, 6].max() - st[:, 6].min()) / 100.0)
@@ -45,6 +54,7 @@ def main():
     lib.sg_debug_read_stamps.argtypes = [C.c_void_p, C.c_int64]
     B = 65536
     env = sg.make_vec("GoalContinuous3P-v0", B, seed=0)
+    env.set_unfused_rollout(True)  # the stamps live in the per-step kernel
     dev = torch.device("cuda", 0)
     K = 260
     acts = torch.rand((K, B, 2), device=dev) * 2 - 1
