@@ -30,13 +30,13 @@ def algorithmic_bytes_per_env_step(env_id):
     return 113 + 16 * s["n_planets"] if s["family"] == "goal" else 109
 
 
-def measured_traffic(env_id, batch):
+def measured_traffic(env_id, batch, steps_per_launch):
     """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 for 16 B/lane streams, WRITE_SIZE), taken
     offline with tools/gpu_profile.sh and committed under profiles/; null when no measurement matches this workload."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if t.get("env_id") == env_id and t.get("batch") == batch:
-            return t["hbm_bytes_per_launch"]
+            return t["hbm_bytes_per_launch"] * steps_per_launch / t["steps_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -211,14 +211,14 @@ def main():
             steps_per_launch = K // launches
             achieved = steps_per_launch * B * bytes_per / (avg_us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.env, B),
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.env, B, steps_per_launch),
                                "kernel": ("goal_rollout_kernel<3>" if steps_per_launch > 1 else "goal_step_kernel<3>")
                                if args.env == "GoalContinuous3P-v0" else "step kernel",
                                "env_steps_per_launch": steps_per_launch * B,
                                "kernel_avg_us": avg_us, "kernel_min_us": kmin * 1e3, "kernel_max_us": kmax * 1e3,
                                "launches": launches, "timing": "hipExtLaunchKernelGGL start/stop events on each of the "
                                f"{launches} dispatches of a second, identical {K}-step pass",
-                               "stream_event_us_per_launch_in_timed_region": stream_ms_per_launch * 1e3,
+                               "stream_event_us_per_step_in_timed_region": stream_ms_per_launch * 1e3,
                                "algorithmic_bytes_per_env_step": bytes_per,
                                "algorithmic_bytes_per_launch": steps_per_launch * B * bytes_per}
             out["value_with_dispatch_events"] = world * B * K / dt_events

@@ -13,19 +13,24 @@ def kernel_rows(path, needle):
     return [r for r in csv.DictReader(open(f[0])) if needle in r["Name"]] if f else []
 
 
-def counter_avg(path, needle):
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def counters_by_kernel(path, needle):
+    """{kernel: {counter: [values per dispatch, in dispatch order]}}"""
     f = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)
+    out = {}
     if not f:
-        return {}
-    agg = {}
+        return out
     for r in csv.DictReader(open(f[0])):
         if needle in r["Kernel_Name"]:
-            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+            out.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return out
 
 
 def main():
-    d, needle = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "goal_step_kernel")
+    d, needle = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "goal_")
     print(f"# profile summary of {os.path.basename(d.rstrip('/'))}; kernel filter: {needle}")
     try:
         b = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
@@ -33,12 +38,15 @@ def main():
     except Exception as e:  # noqa: BLE001
         print("bench.json unreadable:", e)
     print("\n## rocprofv3 --kernel-trace --stats (python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-kernel-timing)")
+    print("## (the rollout kernel is launched twice: 100 warm-up steps, then the 1000 timed steps = MaxNs; the step kernel's")
+    print("##  1000 calls are bench.py's one-launch-per-step A/B pass)")
     for r in kernel_rows(os.path.join(d, "trace"), needle):
-        print({k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")})
-    print("\n## PMC, separate passes, averages per launch of the step kernel (launch count)")
+        print({k: (short(r[k]) if k == "Name" else r[k]) for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")})
+    print("\n## PMC, separate passes; per kernel: mean per dispatch and the largest dispatch (rollout kernel: the 1000-step launch)")
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-        for k, (v, n) in counter_avg(os.path.join(d, sub), needle).items():
-            print(f"{sub}: {k} = {v:.1f}  (n={n})")
+        for kern, cs in counters_by_kernel(os.path.join(d, sub), needle).items():
+            for k, v in cs.items():
+                print(f"{sub}: {kern}: {k}: mean {sum(v) / len(v):.1f} max {max(v):.1f} (n={len(v)})")
 
 
 if __name__ == "__main__":
