@@ -105,14 +105,21 @@ def main():
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal aid: SG_BENCH_REHEARSE=1 runs all ranks on GPU 0 with the gloo backend, to exercise the multi-rank logic on a
+    # one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearse = os.environ.get("SG_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
-    env = sg.make_vec(args.env, B, device=local_rank, seed=args.seed, env_index_base=rank * B)
+    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B)
     D = env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
@@ -129,7 +136,10 @@ def main():
     def sync_all():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if rehearse:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[dev_index])
             torch.cuda.synchronize(dev)
 
     env.reset_torch()
@@ -184,12 +194,13 @@ def main():
         sync_all()
         gather_ms = (time.perf_counter() - t2) * 1e3 / K
 
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    n_done = done[:K].sum(dtype=torch.float64).reshape(1)
+    red_dev = torch.device("cpu") if rehearse else dev
+    stats = torch.tensor([dt, dt_unfused, dt_events or 0.0], device=red_dev, dtype=torch.float64)
+    n_done = done[:K].sum(dtype=torch.float64).reshape(1).to(red_dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(n_done, op=dist.ReduceOp.SUM)
-    dt_max = float(tmax.item())
+    dt_max, dt_unfused, dt_events = float(stats[0]), float(stats[1]), (float(stats[2]) or None)
 
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(args.env)

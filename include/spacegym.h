@@ -34,7 +34,8 @@ typedef struct sg_env sg_env; /* opaque handle */
 
 typedef struct sg_config {
     /* Registered id, as in gym_space/__init__.py:26-146: GoalContinuous{2,3,4}P-v0,
-     * Kepler{CircleOrbit,EllipseEasy,EllipseHard,RandomOrbits}-v0. */
+     * Kepler{CircleOrbit,EllipseEasy,EllipseHard,RandomOrbits}-v0; and the discrete-action ids of keyboard_agent.py:10-74:
+     * GoalDiscrete{2,3,4}-v0, KeplerDiscrete-v0. */
     char env_id[64];
     int64_t num_envs;          /* batch on this device */
     uint64_t seed;             /* SpaceshipEnv.seed, spaceship_env.py:92-94 / goal.py:74-77 */
@@ -53,6 +54,7 @@ const char *sg_last_error(const sg_env *env); /* env may be NULL: last error of 
 int64_t sg_num_envs(const sg_env *env);
 int32_t sg_obs_dim(const sg_env *env);      /* 7 + 2N + 2 (Goal, spaceship_env.py:102-111,124-131); 10 (Kepler, kepler.py:158-187) */
 int32_t sg_num_planets(const sg_env *env);  /* planets with a per-env position: N (Goal), 0 (Kepler) */
+int32_t sg_discrete_actions(const sg_env *env); /* 1 for the ids with Discrete(6) actions (spaceship_env.py:184-187) */
 
 /* SpaceshipEnv.seed (spaceship_env.py:92-94): takes effect at the next reset. */
 int sg_seed(sg_env *env, uint64_t seed);
@@ -64,8 +66,9 @@ int sg_reset_device(sg_env *env, float *obs_dev, void *hip_stream);
 
 /* SpaceshipEnv.step (spaceship_env.py:68-78) for every env, plus what gym.wrappers.TimeLimit and a
  * VectorEnv add around it (elapsed-step counter, truncation, auto-reset).
- *   actions     float32 [num_envs, 2] raw policy output in [-1, 1]^2 (clamped into range on the device;
- *               the reference asserts, spaceship_env.py:71)
+ *   actions     continuous ids: float32 [num_envs, 2] raw policy output in [-1, 1]^2 (clamped into range on the device;
+ *               the reference asserts, spaceship_env.py:71); discrete ids: int32 [num_envs] indices 0..5
+ *               (spaceship_env.py:183-202; out-of-range indices act as 0, the reference raises ValueError)
  *   obs         float32 [num_envs, obs_dim]; for a finished env (auto_reset on) the first observation of
  *               its next episode
  *   reward      float32 [num_envs]
@@ -73,16 +76,16 @@ int sg_reset_device(sg_env *env, float *obs_dev, void *hip_stream);
  *   truncated   uint8   [num_envs]  elapsed == max_episode_steps without a terminal event ("TimeLimit.truncated")
  *   terminal_obs  optional float32 [num_envs, obs_dim]; rows of finished envs receive the last observation of
  *               the episode that ended, other rows are left untouched.  May be NULL. */
-int sg_step(sg_env *env, const float *actions_host, float *obs_host, float *reward_host, uint8_t *done_host,
+int sg_step(sg_env *env, const void *actions_host, float *obs_host, float *reward_host, uint8_t *done_host,
             uint8_t *truncated_host, float *terminal_obs_host);
-int sg_step_device(sg_env *env, const float *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+int sg_step_device(sg_env *env, const void *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                    uint8_t *truncated_dev, float *terminal_obs_dev, void *hip_stream);
 
 /* `n_steps` consecutive steps for pre-supplied actions (open-loop rollout, e.g. random-action benchmarking or replaying an
- * action tape): actions [n_steps, num_envs, 2], obs [n_steps, num_envs, obs_dim], reward/done/truncated [n_steps, num_envs].
+ * action tape): actions [n_steps, num_envs, 2] (discrete ids: int32 [n_steps, num_envs]), obs [n_steps, num_envs, obs_dim], reward/done/truncated [n_steps, num_envs].
  * Bit-identical to n_steps calls of sg_step_device.  All steps run in ONE kernel launch with the env state held in
  * registers; sg_set_unfused_rollout(env, 1) switches to n_steps launches of the step kernel. */
-int sg_rollout_device(sg_env *env, int32_t n_steps, const float *actions_dev, float *obs_dev, float *reward_dev,
+int sg_rollout_device(sg_env *env, int32_t n_steps, const void *actions_dev, float *obs_dev, float *reward_dev,
                       uint8_t *done_dev, uint8_t *truncated_dev, void *hip_stream);
 int sg_set_unfused_rollout(sg_env *env, int32_t on);
 

@@ -36,7 +36,7 @@ class Params(C.Structure):
         ("ref_orbit_a", C.c_double), ("ref_orbit_eccentricity", C.c_double), ("ref_orbit_angle", C.c_double),
         ("numerator_C", C.c_double), ("rad_penalty_C", C.c_double), ("act_penalty_C", C.c_double),
         ("tiling_rows", C.c_int32), ("tiling_cols", C.c_int32), ("tiling_a", C.c_double),
-        ("max_episode_steps", C.c_int32), ("randomize_orbit", C.c_int32),
+        ("max_episode_steps", C.c_int32), ("randomize_orbit", C.c_int32), ("discrete_actions", C.c_int32),
     ]
 
 
@@ -78,14 +78,15 @@ class Oracle:
         self.obs_dim = self.lib.sgo_obs_dim(C.byref(self.params))
         self.n_planets = self.params.n_planets
         self.is_goal = self.params.family == 0
+        self.discrete = bool(self.params.discrete_actions)
         dp, fp, u8 = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
-        self.lib.sgo_env_step_batch.argtypes = [C.POINTER(Params), C.c_int64, dp, dp, dp, fp, dp, dp, u8, u8,
+        self.lib.sgo_env_step_batch.argtypes = [C.POINTER(Params), C.c_int64, dp, dp, dp, C.c_void_p, dp, dp, u8, u8,
                                                 C.POINTER(Diag), C.c_int]
         self.lib.sgo_env_step_batch.restype = None
         es = C.POINTER(EnvState)
         self.lib.sgo_vec_reset.argtypes = [C.POINTER(Params), C.c_uint64, C.c_int64, C.c_uint32, es, dp, C.c_int]
         self.lib.sgo_vec_reset.restype = None
-        self.lib.sgo_vec_step.argtypes = [C.POINTER(Params), C.c_uint64, C.c_int64, C.c_uint32, es, fp, dp, dp, u8, u8,
+        self.lib.sgo_vec_step.argtypes = [C.POINTER(Params), C.c_uint64, C.c_int64, C.c_uint32, es, C.c_void_p, dp, dp, u8, u8,
                                           dp, C.c_int]
         self.lib.sgo_vec_step.restype = None
         self.lib.sgo_env_resample_goal.argtypes = [C.POINTER(Params), C.c_uint64, C.c_uint32, es]
@@ -93,14 +94,23 @@ class Oracle:
         self.lib.sgo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         self.lib.sgo_philox4x32_10.restype = None
 
+    def _actions(self, a, m):
+        """float32 [m, 2] raw actions, or int32 [m] indices for the discrete ids"""
+        if self.discrete:
+            a = np.ascontiguousarray(a, np.int32)
+            assert a.shape == (m,)
+        else:
+            a = np.ascontiguousarray(a, np.float32)
+            assert a.shape == (m, 2)
+        return a
+
     # ---- single transitions on injected inputs (spaceship_env.py:68-78), no reset
     def step(self, state, action, planets=None, goal=None, orbit=None, with_diag=False):
         """state [M,6] f64, action [M,2] raw f32, planets [M,N,2], goal [M,2] (Goal) / orbit [M,3] (Kepler, optional).
         Returns dict(state1, obs, reward, done, goal_hit[, diag])."""
         state = np.ascontiguousarray(state, np.float64).copy()
         m = state.shape[0]
-        action = np.ascontiguousarray(action, np.float32)
-        assert action.shape == (m, 2)
+        action = self._actions(action, m)
         if self.is_goal:
             planets = np.ascontiguousarray(planets, np.float64).reshape(m, self.n_planets * 2)
             aux = np.ascontiguousarray(goal, np.float64).reshape(m, 2)
@@ -111,7 +121,7 @@ class Oracle:
         done = np.empty(m, np.uint8); hit = np.empty(m, np.uint8)
         diag = (Diag * m)() if with_diag else None
         self.lib.sgo_env_step_batch(C.byref(self.params), m, _p(planets, C.c_double), _p(aux, C.c_double),
-                                    _p(state, C.c_double), _p(action, C.c_float), _p(obs, C.c_double),
+                                    _p(state, C.c_double), action.ctypes.data_as(C.c_void_p), _p(obs, C.c_double),
                                     _p(reward, C.c_double), _p(done, C.c_uint8), _p(hit, C.c_uint8), diag, self.threads)
         out = dict(state1=state, obs=obs, reward=reward, done=done, goal_hit=hit)
         if with_diag:
@@ -129,12 +139,11 @@ class Oracle:
 
     def vec_step(self, envs, actions, seed=0, env_id0=0, want_terminal_obs=False):
         b = len(envs)
-        actions = np.ascontiguousarray(actions, np.float32)
-        assert actions.shape == (b, 2)
+        actions = self._actions(actions, b)
         obs = np.empty((b, self.obs_dim)); reward = np.empty(b)
         done = np.empty(b, np.uint8); trunc = np.empty(b, np.uint8)
         tobs = np.full((b, self.obs_dim), np.nan) if want_terminal_obs else None
-        self.lib.sgo_vec_step(C.byref(self.params), seed, b, env_id0, _p(envs, EnvState), _p(actions, C.c_float),
+        self.lib.sgo_vec_step(C.byref(self.params), seed, b, env_id0, _p(envs, EnvState), actions.ctypes.data_as(C.c_void_p),
                               _p(obs, C.c_double), _p(reward, C.c_double), _p(done, C.c_uint8), _p(trunc, C.c_uint8),
                               _p(tobs, C.c_double), self.threads)
         return (obs, reward, done, trunc, tobs) if want_terminal_obs else (obs, reward, done, trunc)

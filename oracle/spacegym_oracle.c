@@ -93,6 +93,18 @@ int sgo_params_for_id(const char *id, sgo_params *out) {
     if (!strcmp(id, "KeplerEllipseHard-v0")) { kepler_params(1.2, 0.725, 3.925, 0, out); return 0; }
     /* constructor defaults kepler.py:193-195 hold until the first reset draws (kepler.py:257-259) */
     if (!strcmp(id, "KeplerRandomOrbits-v0")) { kepler_params(1.2, 0.5, 3.75, 1, out); return 0; }
+    /* discrete-action ids registered by keyboard_agent.py:10-74: max_engine_force = 1 for Goal; KeplerDiscrete-v0 has no
+     * max_episode_steps, i.e. no TimeLimit */
+    if (!strncmp(id, "GoalDiscrete", 12) && id[12] >= '2' && id[12] <= '4' && !strcmp(id + 13, "-v0")) {
+        goal_params(id[12] - '0', out);
+        out->max_engine_force = 1.0; out->discrete_actions = 1;
+        return 0;
+    }
+    if (!strcmp(id, "KeplerDiscrete-v0")) {
+        kepler_params(1.2, 0.0, 0.0, 0, out);
+        out->discrete_actions = 1; out->max_episode_steps = 2147483647;
+        return 0;
+    }
     return -1;
 }
 
@@ -281,11 +293,17 @@ static double brentq(const event_eq *e, double xa, double xb) {
 
 /* dynamic_model.py:94-125 make_step = solve_ivp(RK45, (0, h), y0, events) + wrap angle */
 int sgo_make_step(const sgo_params *p, const double *planets, double *state, const float *action, sgo_diag *diag) {
+    /* dynamic_model.py:170-171: engine_action * max_engine_force in float32 (numpy>=2 keeps f32 * pyfloat in f32) */
+    return sgo_make_step_forces(p, planets, state, (double)(float)(action[0] * (float)p->max_engine_force),
+                                (double)(float)(action[1] * 5.0f) /* dynamic_model.py:140 */, diag);
+}
+
+int sgo_make_step_forces(const sgo_params *p, const double *planets, double *state, double engine_force_scalar,
+                         double omega_cmd, sgo_diag *diag) {
     rhs_ctx c;
     c.p = p; c.planets = planets; c.nfev = 0;
-    /* dynamic_model.py:170-171: engine_action * max_engine_force in float32 (numpy>=2 keeps f32 * pyfloat in f32) */
-    c.engine_force_scalar = (double)(float)(action[0] * (float)p->max_engine_force);
-    c.omega_cmd = (double)(float)(action[1] * 5.0f); /* dynamic_model.py:140 */
+    c.engine_force_scalar = engine_force_scalar;
+    c.omega_cmd = omega_cmd;
 
     const double t0 = 0.0, t_bound = p->step_size;
     double t = t0, y[NEQ], f[NEQ];
@@ -471,6 +489,14 @@ static void rotate(const double *xy, double alpha, double *out) { /* kepler.py:5
 
 double sgo_kepler_reward(const sgo_params *p, const double *s1, const float *action, double a, double ecc,
                          double ref_angle) {
+    /* np.linalg.norm(last_action) on a float32 array stays float32; act_penalty_C * f32 stays f32 */
+    float act_penalty = sqrtf(action[0] * action[0] + action[1] * action[1]);
+    float act_term = (float)p->act_penalty_C * act_penalty;
+    return sgo_kepler_reward_act(p, s1, (double)act_term, a, ecc, ref_angle);
+}
+
+double sgo_kepler_reward_act(const sgo_params *p, const double *s1, double act_term, double a, double ecc,
+                             double ref_angle) {
     const double *pos = s1, *vel = s1 + 3;
     double b = sqrt(a * a * (1 - ecc * ecc)); /* _b */
     double c = sqrt(a * a - b * b);           /* _c */
@@ -497,24 +523,37 @@ double sgo_kepler_reward(const sgo_params *p, const double *s1, const float *act
     double rad_penalty = fabs(cur_rad - target_rad);
     double vel_x_penalty = fabs(V[0] - vel[0]);
     double vel_y_penalty = fabs(V[1] - vel[1]);
-    /* np.linalg.norm(last_action) on a float32 array stays float32; act_penalty_C * f32 stays f32 */
-    float act_penalty = sqrtf(action[0] * action[0] + action[1] * action[1]);
-    float act_term = (float)p->act_penalty_C * act_penalty;
     double C = p->numerator_C;
-    return C / (p->rad_penalty_C * rad_penalty + vel_x_penalty + vel_y_penalty + (double)act_term + C);
+    return C / (p->rad_penalty_C * rad_penalty + vel_x_penalty + vel_y_penalty + act_term + C);
 }
 
 /* ======================================================================================
  * One env.step(): spaceship_env.py:68-78
  * ====================================================================================== */
 void sgo_env_step(const sgo_params *p, const double *planets, const double *goal, double *state,
-                  const float *raw, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit, sgo_diag *diag) {
-    /* ContinuousSpaceshipEnv._translate_raw_action (spaceship_env.py:210-214), float32 arithmetic */
-    float action[2] = {(raw[0] + 1.0f) / 2.0f, raw[1]};
+                  const void *raw_action, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit, sgo_diag *diag) {
+    double efs, omega, act_term;
+    if (p->discrete_actions) {
+        /* DiscreteSpaceshipEnv._translate_raw_action (spaceship_env.py:189-202): python floats -> float64 arithmetic */
+        static const double table[6][2] = {{0, 0}, {1, 0}, {0, -1}, {0, 1}, {1, -1}, {1, 1}};
+        int k = *(const int32_t *)raw_action;
+        if (k < 0 || k > 5) k = 0; /* the reference raises ValueError */
+        const double engine = table[k][0], thruster = table[k][1];
+        efs = engine * p->max_engine_force;   /* dynamic_model.py:171 */
+        omega = thruster * 5.0;               /* dynamic_model.py:140 */
+        act_term = p->act_penalty_C * sqrt(engine * engine + thruster * thruster); /* kepler.py:138,143 in float64 */
+    } else {
+        /* ContinuousSpaceshipEnv._translate_raw_action (spaceship_env.py:210-214), float32 arithmetic */
+        const float *raw = (const float *)raw_action;
+        float action[2] = {(raw[0] + 1.0f) / 2.0f, raw[1]};
+        efs = (double)(float)(action[0] * (float)p->max_engine_force);
+        omega = (double)(float)(action[1] * 5.0f);
+        act_term = (double)((float)p->act_penalty_C * sqrtf(action[0] * action[0] + action[1] * action[1]));
+    }
     double last_xy[2] = {state[0], state[1]}; /* spaceship_env.py:74 */
     static const double origin[2 * SGO_MAX_PLANETS] = {0};
     const double *pl = (p->family == SGO_FAMILY_GOAL) ? planets : origin; /* kepler.py:204-206: both at (0,0) */
-    *done = (uint8_t)sgo_make_step(p, pl, state, action, diag);
+    *done = (uint8_t)sgo_make_step_forces(p, pl, state, efs, omega, diag);
     int hit = 0;
     if (p->family == SGO_FAMILY_GOAL) {
         sgo_make_observation(p, state, pl, goal, obs);
@@ -524,21 +563,22 @@ void sgo_env_step(const sgo_params *p, const double *planets, const double *goal
         double ang = goal ? goal[0] : p->ref_orbit_angle, ecc = goal ? goal[1] : p->ref_orbit_eccentricity;
         double a = goal ? goal[2] : p->ref_orbit_a;
         sgo_make_observation(p, state, pl, goal, obs);
-        *reward = sgo_kepler_reward(p, state, action, a, ecc, ang);
+        *reward = sgo_kepler_reward_act(p, state, act_term, a, ecc, ang);
     }
     *goal_hit = (uint8_t)hit;
 }
 
 void sgo_env_step_batch(const sgo_params *p, int64_t m, const double *planets, const double *goal, double *state,
-                        const float *raw, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit,
+                        const void *raw, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit,
                         sgo_diag *diag, int threads) {
     const int D = sgo_obs_dim(p), n = p->n_planets;
     const int gstride = (p->family == SGO_FAMILY_GOAL) ? 2 : 3;
+    const size_t astride = p->discrete_actions ? sizeof(int32_t) : 2 * sizeof(float);
     (void)threads;
 #pragma omp parallel for schedule(static) num_threads(threads > 1 ? threads : 1)
     for (int64_t i = 0; i < m; i++)
         sgo_env_step(p, planets ? planets + i * 2 * n : NULL, goal ? goal + i * gstride : NULL, state + i * NEQ,
-                     raw + i * 2, obs + i * D, reward + i, done + i, goal_hit + i, diag ? diag + i : NULL);
+                     (const char *)raw + i * astride, obs + i * D, reward + i, done + i, goal_hit + i, diag ? diag + i : NULL);
 }
 
 /* ======================================================================================
@@ -759,16 +799,17 @@ void sgo_vec_reset(const sgo_params *p, uint64_t seed, int64_t b, uint32_t env_i
 }
 
 void sgo_vec_step(const sgo_params *p, uint64_t seed, int64_t b, uint32_t env_id0, sgo_env_state *envs,
-                  const float *raw_actions, double *obs, double *reward, uint8_t *done, uint8_t *truncated,
+                  const void *raw_actions, double *obs, double *reward, uint8_t *done, uint8_t *truncated,
                   double *terminal_obs, int threads) {
     const int D = sgo_obs_dim(p);
+    const size_t astride = p->discrete_actions ? sizeof(int32_t) : 2 * sizeof(float);
     (void)threads;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads > 1 ? threads : 1)
     for (int64_t i = 0; i < b; i++) {
         sgo_env_state *e = &envs[i];
         uint8_t dn, hit;
         sgo_env_step(p, e->planets_xy, p->family == SGO_FAMILY_GOAL ? e->goal_xy : e->orbit, e->state,
-                     raw_actions + 2 * i, obs + i * D, reward + i, &dn, &hit, NULL);
+                     (const char *)raw_actions + i * astride, obs + i * D, reward + i, &dn, &hit, NULL);
         if (hit) sgo_env_resample_goal(p, seed, env_id0 + (uint32_t)i, e); /* goal.py:157 */
         e->elapsed += 1;
         int trunc = !dn && e->elapsed >= p->max_episode_steps; /* gym TimeLimit */

@@ -46,6 +46,7 @@ typedef struct sgo_params {
     double tiling_a;
     int32_t max_episode_steps; /* gym TimeLimit, gym_space/__init__.py:29,45,61,82 */
     int32_t randomize_orbit;   /* KeplerRandomOrbits-v0 */
+    int32_t discrete_actions;  /* DiscreteSpaceshipEnv (spaceship_env.py:183-202): actions are int32 indices 0..5 */
 } sgo_params;
 
 typedef struct sgo_diag {
@@ -63,6 +64,10 @@ int sgo_obs_dim(const sgo_params *p);
  * as float32, like the reference passes it.  state is updated in place. Returns done (0/1). */
 int sgo_make_step(const sgo_params *p, const double *planets_xy, double *state, const float *action,
                   sgo_diag *diag);
+/* Same with the two numbers the RHS derives from the action given directly (float32-rounded for the continuous envs,
+ * float64 for the discrete ones): engine_force_scalar (dynamic_model.py:171) and omega (dynamic_model.py:140). */
+int sgo_make_step_forces(const sgo_params *p, const double *planets_xy, double *state, double engine_force_scalar,
+                         double omega_cmd, sgo_diag *diag);
 
 /* spaceship_env.py:113-131 (+ kepler.py:172-187). */
 void sgo_make_observation(const sgo_params *p, const double *state, const double *planets_xy,
@@ -75,17 +80,20 @@ double sgo_goal_reward(const sgo_params *p, const double *state1, const double *
 /* kepler.py:111-156 with per-call orbit (a, ecc, angle) so RandomOrbits can vary them. */
 double sgo_kepler_reward(const sgo_params *p, const double *state1, const float *action,
                          double ref_a, double ref_ecc, double ref_angle);
+/* act_term = act_penalty_C * ||last_action|| already evaluated (float32 arithmetic for continuous, float64 for discrete) */
+double sgo_kepler_reward_act(const sgo_params *p, const double *state1, double act_term, double ref_a, double ref_ecc,
+                             double ref_angle);
 
 /* spaceship_env.py:68-78: one env.step() on injected inputs, no reset, no goal resample.
- * raw_action is the policy output in [-1,1]^2 (float32).  Outputs: state (in place), obs[D],
- * reward, done, goal_hit. */
+ * raw_action is the policy output: float32[2] in [-1,1]^2, or for the discrete ids one int32 index 0..5.
+ * Outputs: state (in place), obs[D], reward, done, goal_hit. */
 void sgo_env_step(const sgo_params *p, const double *planets_xy, const double *goal_xy, double *state,
-                  const float *raw_action, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit,
+                  const void *raw_action, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit,
                   sgo_diag *diag);
 
 /* Batched form of sgo_env_step over m independent transitions (row-major arrays). threads<=1: serial. */
 void sgo_env_step_batch(const sgo_params *p, int64_t m, const double *planets_xy, const double *goal_xy,
-                        double *state, const float *raw_action, double *obs, double *reward,
+                        double *state, const void *raw_action, double *obs, double *reward,
                         uint8_t *done, uint8_t *goal_hit, sgo_diag *diag, int threads);
 
 /* ---------------------------------------------------------------- reset sampler + vector env
@@ -114,7 +122,7 @@ void sgo_env_resample_goal(const sgo_params *p, uint64_t seed, uint32_t env_id, 
 /* One vector-env step with TimeLimit + auto-reset, mirroring the engine's sg_step semantics
  * (DESIGN.md §step semantics).  obs gets the post-reset observation for finished envs. */
 void sgo_vec_step(const sgo_params *p, uint64_t seed, int64_t b, uint32_t env_id0, sgo_env_state *envs,
-                  const float *raw_actions, double *obs, double *reward, uint8_t *done, uint8_t *truncated,
+                  const void *raw_actions, double *obs, double *reward, uint8_t *done, uint8_t *truncated,
                   double *terminal_obs, int threads);
 void sgo_vec_reset(const sgo_params *p, uint64_t seed, int64_t b, uint32_t env_id0, sgo_env_state *envs,
                    double *obs, int threads);

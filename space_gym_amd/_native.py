@@ -27,6 +27,7 @@ SYMBOLS = {
     "sg_num_envs": (C.c_int64, [_vp]),
     "sg_obs_dim": (C.c_int32, [_vp]),
     "sg_num_planets": (C.c_int32, [_vp]),
+    "sg_discrete_actions": (C.c_int32, [_vp]),
     "sg_seed": (C.c_int, [_vp, C.c_uint64]),
     "sg_set_auto_reset": (C.c_int, [_vp, C.c_int32]),
     "sg_reset": (C.c_int, [_vp, _vp]),

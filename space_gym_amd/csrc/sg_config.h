@@ -21,6 +21,7 @@ typedef struct SgDev {
     uint32_t env_index_base;    /* global index of local env 0 (RNG is keyed by the global index) */
     uint32_t seed_lo, seed_hi;
     int32_t randomize_orbit;    /* KeplerRandomOrbits-v0, kepler.py:257-259 */
+    int32_t discrete_actions;   /* DiscreteSpaceshipEnv (spaceship_env.py:183-202): actions are int32 indices 0..5 */
 
     float h;                    /* step_size 0.07: goal.py:66, gym_space/__init__.py:76 */
     float half_world;           /* world_size / 2: goal.py:10 (3.0), kepler.py:216 (6.0) */

@@ -867,6 +867,22 @@ SG_FN void translate_action(float &a0, float &a1, float max_engine_force, float 
     om = a1 * 5.0f;                 // dynamic_model.py:140
 }
 
+// Raw action of env `idx` from the caller's action buffer: float32 [.., 2] for the continuous ids, int32 [..] for the
+// discrete ones.  DiscreteSpaceshipEnv._translate_raw_action (spaceship_env.py:189-202) maps the index to
+// (engine, thruster) in {0,1} x {-1,0,1}; it is returned as the raw pair (2 engine - 1, thruster) that
+// translate_action() turns back into exactly that (engine, thruster).  Out-of-range indices act as 0 (the reference raises).
+SG_FN void load_action(const SgDev &c, const void *actions, int64_t idx, float &a0, float &a1) {
+    if (c.discrete_actions) {
+        const int k = static_cast<const int32_t *>(actions)[idx];
+        const bool engine = (k == 1) | (k == 4) | (k == 5);
+        a0 = engine ? 1.0f : -1.0f;
+        a1 = (k == 2 || k == 4) ? -1.0f : (k == 3 || k == 5) ? 1.0f : 0.0f;
+    } else {
+        const float *p = static_cast<const float *>(actions) + 2 * idx;
+        a0 = p[0]; a1 = p[1];
+    }
+}
+
 template <int N>
 SG_FN void goal_observe(const SgDev &c, const GoalEnv<N> &e, float (&obs)[7 + 2 * N + 2]) {
     float s, co;

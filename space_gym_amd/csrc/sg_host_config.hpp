@@ -99,6 +99,18 @@ inline int fill_config(const char *id, SgDev &d) {
     if (!std::strcmp(id, "KeplerEllipseEasy-v0")) { fill_kepler(d, 1.2, 0.5, 0.8, 0); return 0; }
     if (!std::strcmp(id, "KeplerEllipseHard-v0")) { fill_kepler(d, 1.2, 0.725, 3.925, 0); return 0; }
     if (!std::strcmp(id, "KeplerRandomOrbits-v0")) { fill_kepler(d, 1.2, 0.5, 3.75, 1); return 0; }  // kepler.py:193-195
+    // discrete-action ids, registered by keyboard_agent.py:10-74 (same classes, Steering.velocity): Goal with
+    // max_engine_force = 1; KeplerDiscrete-v0 without max_episode_steps, i.e. no TimeLimit
+    if (!std::strncmp(id, "GoalDiscrete", 12) && id[12] >= '2' && id[12] <= '4' && !std::strcmp(id + 13, "-v0")) {
+        fill_goal(d, id[12] - '0');
+        d.max_engine_force = 1.0f; d.discrete_actions = 1;
+        return 0;
+    }
+    if (!std::strcmp(id, "KeplerDiscrete-v0")) {
+        fill_kepler(d, 1.2, 0.0, 0.0, 0);
+        d.discrete_actions = 1; d.max_episode_steps = 2147483647;
+        return 0;
+    }
     return -1;
 }
 

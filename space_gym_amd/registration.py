@@ -3,7 +3,7 @@
 this table is what the Python surface exposes (spec lookup, spaces, optional gym registration)."""
 import numpy as np
 
-from .spaces import Box
+from .spaces import Box, Discrete
 
 _GOAL_KW = dict(ship_steering=1, ship_moi=0.01, survival_reward_scale=0.2, goal_vel_reward_scale=5.0,
                 safety_reward_scale=10.0, goal_sparse_reward=5.0, max_engine_force=0.4)
@@ -20,6 +20,16 @@ ENV_SPECS = {
     "KeplerEllipseHard-v0": dict(family="kepler", n_planets=0, max_episode_steps=500,
                                  kwargs=dict(randomize=False, ref_orbit_a=1.2, ref_orbit_eccentricity=0.725, ref_orbit_angle=3.925, **_KEPLER_KW)),
     "KeplerRandomOrbits-v0": dict(family="kepler", n_planets=0, max_episode_steps=500, kwargs=dict(randomize=True, **_KEPLER_KW)),
+    # discrete-action ids (DiscreteSpaceshipEnv, spaceship_env.py:183-202), registered only by keyboard_agent.py:10-74
+    "GoalDiscrete2-v0": dict(family="goal", n_planets=2, max_episode_steps=500, discrete=True,
+                             kwargs=dict(n_planets=2, **{**_GOAL_KW, "max_engine_force": 1})),
+    "GoalDiscrete3-v0": dict(family="goal", n_planets=3, max_episode_steps=500, discrete=True,
+                             kwargs=dict(n_planets=3, **{**_GOAL_KW, "max_engine_force": 1})),
+    "GoalDiscrete4-v0": dict(family="goal", n_planets=4, max_episode_steps=500, discrete=True,
+                             kwargs=dict(n_planets=4, **{**_GOAL_KW, "max_engine_force": 1})),
+    "KeplerDiscrete-v0": dict(family="kepler", n_planets=0, max_episode_steps=None, discrete=True,  # no TimeLimit registered
+                              kwargs=dict(randomize=False, ref_orbit_a=1.2, ref_orbit_eccentricity=0, ref_orbit_angle=0,
+                                          max_engine_force=0.4, reward_value=0, **_KEPLER_KW)),
 }
 
 
@@ -38,7 +48,13 @@ def single_observation_space(env_id):
     return Box(-high, high)
 
 
+def is_discrete(env_id):
+    return bool(ENV_SPECS[env_id].get("discrete"))
+
+
 def single_action_space(env_id):
+    if is_discrete(env_id):
+        return Discrete(2 * 3)  # engine on/off x thruster cw/none/ccw, spaceship_env.py:184-187
     ones = np.ones(2, dtype=np.float32)  # spaceship_env.py:206-208
     return Box(-ones, ones)
 

@@ -16,8 +16,8 @@ import ctypes as C
 import numpy as np
 
 from . import _native
-from .registration import ENV_SPECS, obs_dim, single_action_space, single_observation_space
-from .spaces import batch_box
+from .registration import ENV_SPECS, is_discrete, obs_dim, single_action_space, single_observation_space
+from .spaces import MultiDiscrete, batch_box
 
 
 class StepInfo(dict):
@@ -40,7 +40,9 @@ class SpaceGymVectorEnv:
         self.single_observation_space = single_observation_space(env_id)
         self.single_action_space = single_action_space(env_id)
         self.observation_space = batch_box(self.single_observation_space, self.num_envs)
-        self.action_space = batch_box(self.single_action_space, self.num_envs)
+        self.discrete = is_discrete(env_id)
+        self.action_space = (MultiDiscrete([self.single_action_space.n] * self.num_envs) if self.discrete
+                             else batch_box(self.single_action_space, self.num_envs))
         self.validate_actions = validate_actions
         self.want_terminal_obs = terminal_observation
         cfg = _native.SgConfig(env_id=env_id.encode(), num_envs=self.num_envs, seed=int(seed),
@@ -94,6 +96,13 @@ class SpaceGymVectorEnv:
         return self._obs.copy()
 
     def _check_actions(self, actions):
+        if self.discrete:  # int index per env, spaceship_env.py:189-202
+            actions = np.ascontiguousarray(actions, dtype=np.int32)
+            if actions.shape != (self.num_envs,):
+                raise ValueError(f"actions must have shape ({self.num_envs},), got {actions.shape}")
+            if self.validate_actions and not (np.all(actions >= 0) and np.all(actions <= 5)):
+                raise ValueError("discrete action out of range")  # the reference raises ValueError, spaceship_env.py:201-202
+            return actions
         actions = np.ascontiguousarray(actions, dtype=np.float32)  # raw_action.astype(np.float32), spaceship_env.py:69-70
         if actions.shape != (self.num_envs, 2):
             raise ValueError(f"actions must have shape ({self.num_envs}, 2), got {actions.shape}")
@@ -172,7 +181,8 @@ class SpaceGymVectorEnv:
         by the next call unless `out` (a dict with the same keys) is given."""
         torch, bufs = self._torch()
         o = bufs if out is None else out
-        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous() and tuple(actions.shape) == (self.num_envs, 2)
+        want = (torch.int32, (self.num_envs,)) if self.discrete else (torch.float32, (self.num_envs, 2))
+        assert actions.is_cuda and actions.is_contiguous() and (actions.dtype, tuple(actions.shape)) == want, want
         rc = self._lib.sg_step_device(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(o["obs"].data_ptr()),
                                       C.c_void_p(o["reward"].data_ptr()), C.c_void_p(o["done"].data_ptr()),
                                       C.c_void_p(o["trunc"].data_ptr()),
@@ -181,7 +191,7 @@ class SpaceGymVectorEnv:
         return o["obs"], o["reward"], o["done"], o["trunc"]
 
     def rollout_torch(self, actions, obs, reward, done, trunc):
-        """actions [K, B, 2] -> obs [K, B, D], reward/done/trunc [K, B]: K steps enqueued back to back."""
+        """actions [K, B, 2] (discrete ids: int32 [K, B]) -> obs [K, B, D], reward/done/trunc [K, B]: K steps, one launch."""
         K = actions.shape[0]
         rc = self._lib.sg_rollout_device(self._h, int(K), C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
                                          C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),

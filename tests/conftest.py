@@ -17,6 +17,11 @@ FAMILIES = {
     "kepler_circle": "KeplerCircleOrbit-v0",
     "kepler_easy": "KeplerEllipseEasy-v0",
     "kepler_hard": "KeplerEllipseHard-v0",
+    # discrete-action ids of keyboard_agent.py:10-74
+    "goal_discrete2": "GoalDiscrete2-v0",
+    "goal_discrete3": "GoalDiscrete3-v0",
+    "goal_discrete4": "GoalDiscrete4-v0",
+    "kepler_discrete": "KeplerDiscrete-v0",
 }
 
 

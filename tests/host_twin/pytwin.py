@@ -20,18 +20,19 @@ class Twin:
         self.obs_dim = self.lib.twin_obs_dim(self.env_id)
         assert self.obs_dim > 0
         self.is_goal = env_id.startswith("Goal")
+        self.discrete = "Discrete" in env_id
         self.n_planets = (self.obs_dim - 9) // 2 if self.is_goal else 0
 
     def step(self, state, action, planets=None, goal=None):
         state = np.ascontiguousarray(state, np.float32); m = len(state)
-        action = np.ascontiguousarray(action, np.float32)
+        action = np.ascontiguousarray(action, np.int32 if self.discrete else np.float32)
         planets = np.ascontiguousarray(planets, np.float32) if planets is not None else None
         goal = np.ascontiguousarray(goal, np.float32) if goal is not None else None
         out = dict(state1=np.empty((m, 6), np.float32), obs=np.empty((m, self.obs_dim), np.float32),
                    reward=np.empty(m, np.float32), done=np.empty(m, np.uint8), goal_hit=np.empty(m, np.uint8),
                    t=np.empty(m, np.float32), n_rk=np.empty(m, np.int32), event=np.empty(m, np.int32))
         f, u8, i32 = C.c_float, C.c_uint8, C.c_int32
-        rc = self.lib.twin_step(self.env_id, C.c_int64(m), _p(state, f), _p(planets, f), _p(goal, f), _p(action, f),
+        rc = self.lib.twin_step(self.env_id, C.c_int64(m), _p(state, f), _p(planets, f), _p(goal, f), action.ctypes.data_as(C.c_void_p),
                                 _p(out["state1"], f), _p(out["obs"], f), _p(out["reward"], f), _p(out["done"], u8),
                                 _p(out["goal_hit"], u8), _p(out["t"], f), _p(out["n_rk"], i32), _p(out["event"], i32))
         assert rc == 0

@@ -12,7 +12,7 @@ using namespace sg;
 
 template <int N>
 static void goal_steps(const SgDev &c, int64_t m, const float *state, const float *planets, const float *goal,
-                       const float *action, float *state1, float *obs, float *reward, uint8_t *done, uint8_t *hit,
+                       const void *action, float *state1, float *obs, float *reward, uint8_t *done, uint8_t *hit,
                        float *t_adv, int32_t *n_rk, int32_t *event) {
     constexpr int D = 7 + 2 * N + 2;
     for (int64_t i = 0; i < m; i++) {
@@ -24,7 +24,9 @@ static void goal_steps(const SgDev &c, int64_t m, const float *state, const floa
         float o[D], r;
         int dn, ht;
         StepResult sr;
-        goal_env_step<N>(c, e, action[2 * i], action[2 * i + 1], o, r, dn, ht, sr);
+        float a0, a1;
+        load_action(c, action, i, a0, a1);
+        goal_env_step<N>(c, e, a0, a1, o, r, dn, ht, sr);
         float *s1 = state1 + 6 * i;
         s1[0] = e.x; s1[1] = e.y; s1[2] = e.th; s1[3] = e.vx; s1[4] = e.vy; s1[5] = e.om;
         std::memcpy(obs + D * i, o, sizeof(o));
@@ -41,7 +43,7 @@ extern "C" int twin_obs_dim(const char *env_id) {
 
 // Kepler: `goal` may carry a per-env orbit (phi, ecc) as for KeplerRandomOrbits-v0 (the engine stores cos/sin phi in fp64)
 extern "C" int twin_step(const char *env_id, int64_t m, const float *state, const float *planets, const float *goal,
-                         const float *action, float *state1, float *obs, float *reward, uint8_t *done, uint8_t *hit,
+                         const void *action, float *state1, float *obs, float *reward, uint8_t *done, uint8_t *hit,
                          float *t_adv, int32_t *n_rk, int32_t *event) {
     SgDev c;
     if (fill_config(env_id, c)) return -1;
@@ -65,7 +67,9 @@ extern "C" int twin_step(const char *env_id, int64_t m, const float *state, cons
         float o[10], r;
         int dn;
         StepResult sr;
-        kepler_env_step(c, ob, e, action[2 * i], action[2 * i + 1], o, r, dn, sr);
+        float a0, a1;
+        load_action(c, action, i, a0, a1);
+        kepler_env_step(c, ob, e, a0, a1, o, r, dn, sr);
         float *s1 = state1 + 6 * i;
         s1[0] = e.x; s1[1] = e.y; s1[2] = e.th; s1[3] = e.vx; s1[4] = e.vy; s1[5] = e.om;
         std::memcpy(obs + 10 * i, o, sizeof(o));

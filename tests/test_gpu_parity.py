@@ -59,6 +59,7 @@ def test_step_matches_reference_golden(fam, golden_steps):
         changed = np.any(st["goal"] != d["goal"].astype(np.float32), axis=1)
         assert np.array_equal(changed, d["goal_changed"].astype(bool))
     assert np.array_equal(st["elapsed"], np.ones(m, np.int32))
+    assert env.discrete == ("discrete" in fam)
     env.close()
 
 
@@ -239,14 +240,18 @@ def test_device_tensor_path_matches_host_path():
 
 
 @pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0",
-                                    "KeplerRandomOrbits-v0"])
+                                    "KeplerRandomOrbits-v0", "GoalDiscrete3-v0", "KeplerDiscrete-v0"])
 def test_fused_rollout_equals_step_by_step(env_id):
     """sg_rollout_device (Goal: ONE launch for K steps, state in registers, restarts handed back through shuffles) is
     bit-identical to K launches of the step kernel: outputs of every step and the final state, through several
     generations of episodes and goal resamples."""
     import torch
     n, K = 8192, 300
-    a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    if "Discrete" in env_id:
+        a = torch.randint(0, 6, (K, n), device="cuda", generator=gen, dtype=torch.int32)
+    else:
+        a = torch.rand((K, n, 2), device="cuda", generator=gen) * 2 - 1
     outs = []
     for mode in (0, 1):  # one K-step launch (default) | one launch per step
         env = make(env_id, n, seed=21, max_episode_steps=120)

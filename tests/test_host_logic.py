@@ -40,7 +40,9 @@ def test_spaces_mirror_the_reference():
     from space_gym_amd.registration import ENV_SPECS, obs_dim, single_action_space, single_observation_space
     assert {k: obs_dim(k) for k in ENV_SPECS} == {
         "GoalContinuous2P-v0": 13, "GoalContinuous3P-v0": 15, "GoalContinuous4P-v0": 17, "KeplerCircleOrbit-v0": 10,
-        "KeplerEllipseEasy-v0": 10, "KeplerEllipseHard-v0": 10, "KeplerRandomOrbits-v0": 10}
+        "KeplerEllipseEasy-v0": 10, "KeplerEllipseHard-v0": 10, "KeplerRandomOrbits-v0": 10,
+        "GoalDiscrete2-v0": 13, "GoalDiscrete3-v0": 15, "GoalDiscrete4-v0": 17, "KeplerDiscrete-v0": 10}
+    assert single_action_space("GoalDiscrete3-v0").n == 6 and single_action_space("GoalDiscrete3-v0").contains(5)
     sp = single_observation_space("GoalContinuous3P-v0")
     assert sp.shape == (15,) and sp.dtype == np.float32
     assert np.isinf(sp.high[4:6]).all() and np.allclose(sp.high[7:], 2 * np.sqrt(2)) and np.array_equal(sp.low, -sp.high)

@@ -28,8 +28,9 @@ def test_oracle_matches_reference_golden(fam, golden_steps):
     assert np.array_equal(r["done"], d["done"])
     assert np.array_equal(r["goal_hit"], d["goal_changed"])
     assert np.abs(r["state1"] - d["state1"]).max() <= TOL_STATE
-    assert np.abs(r["state1"] - d["core_state1"]).max() <= TOL_STATE  # no-shim make_step fixtures
-    assert np.array_equal(r["done"], d["core_done"])
+    if "core_state1" in d:  # no-shim make_step fixtures (continuous ids)
+        assert np.abs(r["state1"] - d["core_state1"]).max() <= TOL_STATE
+        assert np.array_equal(r["done"], d["core_done"])
     assert np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
     assert np.abs(r["reward"] - d["reward"]).max() <= TOL_REWARD
     # same adaptive-step decisions as scipy's RK45 controller and the same terminal event
@@ -53,7 +54,7 @@ def test_golden_covers_the_edge_cases(fam, golden_steps):
     else:
         assert {0, 1} <= set(ev.tolist())  # central planet and border circle
     assert {1, 2} <= set(d["n_rk_steps"].tolist())
-    assert (d["done"] == 1).sum() >= 400 and (d["done"] == 0).sum() >= 1200
+    assert (d["done"] == 1).sum() >= (150 if "discrete" in fam else 400) and (d["done"] == 0).sum() >= (500 if "discrete" in fam else 1200)
     # inputs are fp32-representable so the fp32 engine sees exactly what the reference saw
     for k in ("state0", "planets", "goal"):
         if k in d:
@@ -64,7 +65,11 @@ def test_invariants_of_reference_outputs(golden_steps):
     """omega == float32(5*a1); theta in [0, 2pi); terminal state sits on a boundary."""
     for fam, d in golden_steps.items():
         s1 = d["state1"]
-        assert np.array_equal(s1[:, 5], (d["action"][:, 1] * np.float32(5.0)).astype(np.float64))
+        if "discrete" in fam:  # thruster in {-1, 0, 1} from the action table (spaceship_env.py:189-202)
+            thr = np.array([0.0, 0.0, -1.0, 1.0, -1.0, 1.0])[d["action"]]
+            assert np.array_equal(s1[:, 5], thr * 5.0)
+        else:
+            assert np.array_equal(s1[:, 5], (d["action"][:, 1] * np.float32(5.0)).astype(np.float64))
         assert (s1[:, 2] >= 0).all() and (s1[:, 2] < 2 * np.pi).all()
         o = Oracle(FAMILIES[fam])
         half = o.params.world_size / 2

@@ -41,6 +41,22 @@ FAMILIES = {
     "kepler_easy": "KeplerEllipseEasy-v0",
     "kepler_hard": "KeplerEllipseHard-v0",
 }
+# Discrete-action ids: registered only by keyboard_agent.py:10-74 (not by gym_space/__init__.py); same classes, kwargs below.
+DISCRETE_FAMILIES = {
+    "goal_discrete2": ("GoalDiscrete2-v0", "GoalDiscreteEnv", dict(n_planets=2, ship_steering=1, ship_moi=0.01, survival_reward_scale=0.2,
+                                                                   goal_vel_reward_scale=5.0, safety_reward_scale=10.0,
+                                                                   goal_sparse_reward=5.0, max_engine_force=1)),
+    "goal_discrete3": ("GoalDiscrete3-v0", "GoalDiscreteEnv", dict(n_planets=3, ship_steering=1, ship_moi=0.01, survival_reward_scale=0.2,
+                                                                   goal_vel_reward_scale=5.0, safety_reward_scale=10.0,
+                                                                   goal_sparse_reward=5.0, max_engine_force=1)),
+    "goal_discrete4": ("GoalDiscrete4-v0", "GoalDiscreteEnv", dict(n_planets=4, ship_steering=1, ship_moi=0.01, survival_reward_scale=0.2,
+                                                                   goal_vel_reward_scale=5.0, safety_reward_scale=10.0,
+                                                                   goal_sparse_reward=5.0, max_engine_force=1)),
+    "kepler_discrete": ("KeplerDiscrete-v0", "KeplerDiscreteEnv", dict(ship_steering=1, ship_moi=0.01, max_engine_force=0.4, reward_value=0,
+                                                                       rad_penalty_C=2, numerator_C=0.01, act_penalty_C=0.5, step_size=0.07,
+                                                                       randomize=False, ref_orbit_a=1.2, ref_orbit_eccentricity=0,
+                                                                       ref_orbit_angle=0)),
+}
 STEP_SIZE = 0.07
 MAX_EPISODE_STEPS = 500
 # thrust 0.4 over a 3..6 unit world bounds natural speeds at ~1.6..2.2; forced cases stay below this
@@ -133,11 +149,19 @@ def snapshot_inputs(env):
     return d
 
 
+def is_discrete(env):
+    return hasattr(env.action_space, "n")
+
+
 def step_and_record(env, rec, action, kind):
     row = snapshot_inputs(env)
-    row["action"] = np.asarray(action, dtype=np.float32)
     goal_before = env.goal_pos.copy() if is_goal(env) else None
-    obs, reward, done, _ = env.step(row["action"].copy())
+    if is_discrete(env):
+        row["action"] = np.int32(action)
+        obs, reward, done, _ = env.step(int(action))
+    else:
+        row["action"] = np.asarray(action, dtype=np.float32)
+        obs, reward, done, _ = env.step(row["action"].copy())
     row["state1"] = np.array(env._ship_state._state_vec, dtype=np.float64)
     row["obs"] = np.array(obs, dtype=np.float64)
     row["reward"] = float(reward)
@@ -159,7 +183,7 @@ def rollout_rows(env, rec, rng, n_steps, n_keep_nonterminal):
     quantise_env(env)
     elapsed = 0
     for _ in range(n_steps):
-        a = rng.uniform(-1, 1, size=2).astype(np.float32)
+        a = rng.randint(6) if is_discrete(env) else rng.uniform(-1, 1, size=2).astype(np.float32)
         row, done = step_and_record(env, rec, a, KINDS.index("rollout"))
         elapsed += 1
         (rows_t if (done or row["goal_changed"]) else rows_n).append(row)
@@ -200,7 +224,8 @@ def forced_goal_rows(env, rec, rng, n_each):
 
     def run(state, planets, goal, kind, extreme=False):
         inject(env, state, planets, q32(goal))
-        row, _ = step_and_record(env, rec, rand_action(rng, extreme), KINDS.index(kind))
+        a = rng.randint(6) if is_discrete(env) else rand_action(rng, extreme)
+        row, _ = step_and_record(env, rec, a, KINDS.index(kind))
         rows.append(row)
 
     for _ in range(n_each):  # walls: +x, -x, +y, -y
@@ -264,7 +289,10 @@ def forced_kepler_rows(env, rec, rng, n_each):
 
     def run(state, kind, action=None):
         inject(env, state)
-        a = rand_action(rng) if action is None else np.asarray(action, dtype=np.float32)
+        if is_discrete(env):
+            a = rng.randint(6) if (action is None or kind != "near_orbit") else 0  # 0 = engine off, no thruster
+        else:
+            a = rand_action(rng) if action is None else np.asarray(action, dtype=np.float32)
         row, _ = step_and_record(env, rec, a, KINDS.index(kind))
         rows.append(row)
 
@@ -448,6 +476,26 @@ def stage_env(args):
               f"{int(arrs['goal_changed'].sum())} goal hits -> {path}", flush=True)
 
 
+def stage_discrete(args):
+    """Discrete-action variants (DiscreteSpaceshipEnv._translate_raw_action, spaceship_env.py:189-202)."""
+    registry, envs, dynamic_model = load_env_layer()
+    rec = IvpRecorder(dynamic_model)
+    for fam, (env_id, cls_name, kwargs) in DISCRETE_FAMILIES.items():
+        rng = np.random.RandomState(sum(map(ord, fam)) * 7919 % (1 << 31))
+        with contextlib.redirect_stdout(io.StringIO()):
+            env = getattr(envs, cls_name)(**kwargs)
+        rows = rollout_rows(env, rec, rng, args.rollout_steps // 2, args.keep_nonterminal // 2)
+        rows += (forced_goal_rows if is_goal(env) else forced_kepler_rows)(env, rec, rng, args.forced_each // 2)
+        arrs = rows_to_arrays(rows, is_goal(env))
+        arrs.update(env_constants(env))
+        arrs["kind_names"] = np.array(KINDS)
+        arrs["env_id"] = np.array(env_id)
+        path = os.path.join(OUT, f"step_{fam}.npz")
+        np.savez_compressed(path, **arrs)
+        print(f"{fam}: {len(rows)} transitions, {int(arrs['done'].sum())} terminal, "
+              f"{int(arrs['goal_changed'].sum())} goal hits -> {path}", flush=True)
+
+
 def stage_reset(args):
     registry, envs, _ = load_env_layer()
     os.makedirs(OUT, exist_ok=True)
@@ -492,14 +540,14 @@ def stage_core(_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stage", choices=["all", "env", "core", "reset"], default="all")
+    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete"], default="all")
     ap.add_argument("--rollout-steps", type=int, default=20000)
     ap.add_argument("--keep-nonterminal", type=int, default=1200)
     ap.add_argument("--forced-each", type=int, default=80)
     ap.add_argument("--n-resets", type=int, default=100000)
     args = ap.parse_args()
     if args.stage == "all":
-        for st in ("env", "core", "reset"):
+        for st in ("env", "core", "reset", "discrete"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--stage", st,
                                    "--rollout-steps", str(args.rollout_steps),
                                    "--keep-nonterminal", str(args.keep_nonterminal),
@@ -508,6 +556,8 @@ def main():
         stage_env(args)
     elif args.stage == "reset":
         stage_reset(args)
+    elif args.stage == "discrete":
+        stage_discrete(args)
     else:
         stage_core(args)
 
