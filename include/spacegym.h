@@ -19,6 +19,7 @@
 #ifndef SPACEGYM_H
 #define SPACEGYM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -97,6 +98,11 @@ int sg_set_unfused_rollout(sg_env *env, int32_t on);
  *   elapsed int32   [num_envs]      steps taken in the current episode */
 int sg_get_state(sg_env *env, float *ship, float *planets, float *goal, int32_t *elapsed);
 int sg_set_state(sg_env *env, const float *ship, const float *planets, const float *goal, const int32_t *elapsed);
+
+/* Page-locked host memory for the arrays passed to sg_reset / sg_step (optional: any host memory works, pinned memory
+ * makes the per-step copies plain DMA).  sg_host_alloc returns NULL on failure. */
+void *sg_host_alloc(size_t bytes);
+void sg_host_free(void *ptr);
 
 /* Measurement aid (no reference counterpart): with profiling on, each step-kernel launch carries start/stop events
  * that timestamp the dispatch itself; sg_get_profile returns and clears the durations recorded so far (milliseconds).

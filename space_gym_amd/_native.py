@@ -38,6 +38,8 @@ SYMBOLS = {
     "sg_set_unfused_rollout": (C.c_int, [_vp, C.c_int32]),
     "sg_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sg_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sg_host_alloc": (_vp, [C.c_size_t]),
+    "sg_host_free": (None, [_vp]),
     "sg_set_profiling": (C.c_int, [_vp, C.c_int32]),
     "sg_get_profile": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sg_stream": (_vp, [_vp]),

@@ -29,7 +29,9 @@ class SpaceGymVectorEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, env_id, num_envs, device=0, seed=0, env_index_base=0, max_episode_steps=None, auto_reset=True,
-                 validate_actions=False, terminal_observation=True):
+                 validate_actions=False, terminal_observation=True, copy=True):
+        """copy=False: reset()/step() return views of the engine's pinned output buffers, overwritten by the next call
+        (no per-step allocation or copy); copy=True returns fresh arrays like gym's vector envs."""
         if env_id not in ENV_SPECS:
             raise ValueError(f"unknown env id {env_id!r}; served ids: {sorted(ENV_SPECS)}")
         self._lib = _native.load()
@@ -54,19 +56,37 @@ class SpaceGymVectorEnv:
         self._h = h
         assert self._lib.sg_obs_dim(h) == self.obs_dim
         B, D = self.num_envs, self.obs_dim
-        self._obs = np.empty((B, D), np.float32)
-        self._rew = np.empty(B, np.float32)
-        self._done = np.empty(B, np.uint8)
-        self._trunc = np.empty(B, np.uint8)
-        self._tobs = np.full((B, D), np.nan, np.float32) if terminal_observation else None
+        self.copy = bool(copy)
+        self._pinned = []
+        self._obs = self._host_array((B, D), np.float32)
+        self._rew = self._host_array((B,), np.float32)
+        self._done = self._host_array((B,), np.uint8)
+        self._trunc = self._host_array((B,), np.uint8)
+        self._act = self._host_array((B,) if self.discrete else (B, 2), np.int32 if self.discrete else np.float32)
+        self._tobs = self._host_array((B, D), np.float32) if terminal_observation else None
+        if self._tobs is not None:
+            self._tobs.fill(np.nan)
         self._pending = None
         self._torch_bufs = None
+
+    def _host_array(self, shape, dtype):
+        """NumPy array over page-locked memory (sg_host_alloc); ordinary memory if pinning fails."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self._lib.sg_host_alloc(n)
+        if not ptr:
+            return np.empty(shape, dtype)
+        self._pinned.append(ptr)
+        return np.frombuffer((C.c_char * n).from_address(ptr), dtype=dtype).reshape(shape)
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         if getattr(self, "_h", None):
             self._lib.sg_destroy(self._h)
             self._h = None
+            self._obs = self._rew = self._done = self._trunc = self._act = self._tobs = None
+            for ptr in self._pinned:
+                self._lib.sg_host_free(ptr)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -93,7 +113,7 @@ class SpaceGymVectorEnv:
 
     def reset(self):
         self._ck(self._lib.sg_reset(self._h, self._ptr(self._obs)), "sg_reset")
-        return self._obs.copy()
+        return self._obs.copy() if self.copy else self._obs
 
     def _check_actions(self, actions):
         if self.discrete:  # int index per env, spaceship_env.py:189-202
@@ -117,13 +137,16 @@ class SpaceGymVectorEnv:
         a, self._pending = self._pending, None
         if a is None:
             raise RuntimeError("step_wait() without step_async()")
-        rc = self._lib.sg_step(self._h, self._ptr(a), self._ptr(self._obs), self._ptr(self._rew), self._ptr(self._done),
-                               self._ptr(self._trunc), self._ptr(self._tobs))
+        np.copyto(self._act, a)  # into the pinned action buffer
+        rc = self._lib.sg_step(self._h, self._ptr(self._act), self._ptr(self._obs), self._ptr(self._rew),
+                               self._ptr(self._done), self._ptr(self._trunc), self._ptr(self._tobs))
         self._ck(rc, "sg_step")
-        info = StepInfo({"TimeLimit.truncated": self._trunc.astype(bool)})
+        info = StepInfo({"TimeLimit.truncated": self._trunc.view(np.bool_) if not self.copy else self._trunc.astype(bool)})
         if self._tobs is not None:
-            info["terminal_observation"] = self._tobs.copy()
-        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), info
+            info["terminal_observation"] = self._tobs.copy() if self.copy else self._tobs
+        if self.copy:
+            return self._obs.copy(), self._rew.copy(), self._done.astype(bool), info
+        return self._obs, self._rew, self._done.view(np.bool_), info
 
     def step(self, actions):
         self.step_async(actions)

