@@ -334,3 +334,16 @@ def test_step_device_is_graph_capturable():
         torch.cuda.synchronize()
         assert torch.equal(out["obs"], ob) and torch.equal(out["reward"], rw) and torch.equal(out["done"], dn)
     eager.close(); graphed.close()
+
+
+def test_random_orbits_match_reference_golden():
+    """Per-env orbits injected through set_state(goal=(angle, eccentricity)); outputs against the reference fixture."""
+    from conftest import load_golden
+    d = load_golden("step_kepler_random")
+    m = len(d["state0"])
+    env = make("KeplerRandomOrbits-v0", m, seed=1, auto_reset=False)
+    env.reset()
+    env.set_state(ship=d["state0"], goal=d["orbit"][:, :2], elapsed=np.zeros(m, np.int32))
+    obs, rew, done, info = env.step(d["action"])
+    check_against(obs, rew, done, env.get_state()["ship"], d["state1"], d["obs"], d["reward"], d["done"])
+    env.close()

@@ -232,3 +232,13 @@ def test_event_roots_on_grazing_and_corner_cases(env_id):
     assert np.abs(tw["state1"][:, [0, 1, 3, 4, 5]] - ref["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
     assert np.abs(tw["obs"] - ref["obs"]).max() <= TOL_OBS
     assert (np.abs(tw["reward"] - ref["reward"]) / np.maximum(1, np.abs(ref["reward"]))).max() <= TOL_REWARD_REL
+
+
+def test_random_orbits_match_reference_golden():
+    from conftest import load_golden
+    d = load_golden("step_kepler_random")
+    tw = Twin("KeplerRandomOrbits-v0").step(d["state0"], d["action"], goal=d["orbit"][:, :2].astype(np.float32))
+    assert np.array_equal(tw["done"], d["done"])
+    assert np.abs(tw["state1"][:, [0, 1, 3, 4, 5]] - d["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
+    assert np.abs(tw["obs"] - d["obs"]).max() <= TOL_OBS
+    assert (np.abs(tw["reward"] - d["reward"]) / np.maximum(1, np.abs(d["reward"]))).max() <= TOL_REWARD_REL

@@ -80,3 +80,14 @@ def test_invariants_of_reference_outputs(golden_steps):
         wall = half - np.abs(s1[:, :2]).max(axis=1)
         g = np.minimum(np.abs(dist).min(axis=1), np.abs(wall))
         assert g[term].max() < 1e-9
+
+
+def test_oracle_matches_reference_random_orbits():
+    """KeplerRandomOrbits-v0 (randomize=True, kepler.py:257-259): per-row (angle, eccentricity) captured from the reference."""
+    from conftest import load_golden
+    d = load_golden("step_kepler_random")
+    r = Oracle("KeplerRandomOrbits-v0").step(d["state0"], d["action"], orbit=d["orbit"], with_diag=True)
+    assert np.array_equal(r["done"], d["done"]) and np.array_equal(r["diag"]["n_rk_steps"], d["n_rk_steps"])
+    assert np.abs(r["state1"] - d["state1"]).max() <= TOL_STATE and np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
+    assert np.abs(r["reward"] - d["reward"]).max() <= TOL_REWARD
+    assert d["orbit"][:, 1].std() > 0.1  # eccentricities really vary

@@ -496,6 +496,44 @@ def stage_discrete(args):
               f"{int(arrs['goal_changed'].sum())} goal hits -> {path}", flush=True)
 
 
+def stage_random_orbits(args):
+    """KeplerRandomOrbits-v0 (randomize=True, kepler.py:257-259): every row carries its own (angle, eccentricity)."""
+    registry, envs, dynamic_model = load_env_layer()
+    rec = IvpRecorder(dynamic_model)
+    env = make_env(registry, envs, "KeplerRandomOrbits-v0")
+    rng = np.random.RandomState(4242)
+    np.random.seed(99)  # the reference draws the orbit from the GLOBAL numpy RNG
+    rows = []
+    env.seed(7); env.reset()
+    elapsed = 0
+    for _ in range(args.rollout_steps // 2):
+        # fp32-representable orbit parameters, like every other engine input
+        env.ref_orbit_angle = float(np.float32(env.ref_orbit_angle)); env.ref_orbit_eccentricity = float(np.float32(env.ref_orbit_eccentricity))
+        inject(env, q32(env._ship_state._state_vec))
+        a = rng.uniform(-1, 1, size=2).astype(np.float32)
+        if rng.uniform() < 0.2:
+            a = np.array([-1.0, 0.0], np.float32)  # engine off: the sensitive regime of the reward
+        orbit = np.array([env.ref_orbit_angle, env.ref_orbit_eccentricity, env.ref_orbit_a])
+        row, done = step_and_record(env, rec, a, KINDS.index("rollout"))
+        row["orbit"] = orbit
+        rows.append(row)
+        elapsed += 1
+        if done or elapsed >= MAX_EPISODE_STEPS:
+            env.reset(); elapsed = 0
+    keep_t = [r for r in rows if r["done"]]
+    keep_n = [r for r in rows if not r["done"]]
+    sel = rng.choice(len(keep_n), size=min(args.keep_nonterminal, len(keep_n)), replace=False)
+    rows = keep_t + [keep_n[i] for i in sorted(sel)]
+    arrs = rows_to_arrays(rows, False)
+    arrs["orbit"] = np.array([r["orbit"] for r in rows])
+    arrs.update(env_constants(env))
+    arrs["kind_names"] = np.array(KINDS); arrs["env_id"] = np.array("KeplerRandomOrbits-v0")
+    path = os.path.join(OUT, "step_kepler_random.npz")
+    np.savez_compressed(path, **arrs)
+    print(f"kepler_random: {len(rows)} transitions, {int(arrs['done'].sum())} terminal, ecc range "
+          f"[{arrs['orbit'][:, 1].min():.3f}, {arrs['orbit'][:, 1].max():.3f}] -> {path}", flush=True)
+
+
 def stage_reset(args):
     registry, envs, _ = load_env_layer()
     os.makedirs(OUT, exist_ok=True)
@@ -540,14 +578,14 @@ def stage_core(_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete"], default="all")
+    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete", "random_orbits"], default="all")
     ap.add_argument("--rollout-steps", type=int, default=20000)
     ap.add_argument("--keep-nonterminal", type=int, default=1200)
     ap.add_argument("--forced-each", type=int, default=80)
     ap.add_argument("--n-resets", type=int, default=100000)
     args = ap.parse_args()
     if args.stage == "all":
-        for st in ("env", "core", "reset", "discrete"):
+        for st in ("env", "core", "reset", "discrete", "random_orbits"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--stage", st,
                                    "--rollout-steps", str(args.rollout_steps),
                                    "--keep-nonterminal", str(args.keep_nonterminal),
@@ -558,6 +596,8 @@ def main():
         stage_reset(args)
     elif args.stage == "discrete":
         stage_discrete(args)
+    elif args.stage == "random_orbits":
+        stage_random_orbits(args)
     else:
         stage_core(args)
 
