@@ -42,6 +42,11 @@ def measured_traffic(env_id, batch, steps_per_launch):
     return None
 
 
+def obs_dim_of(env_id):
+    from space_gym_amd.registration import obs_dim
+    return obs_dim(env_id)
+
+
 def usable_cores():
     """CPU share of this process: the cgroup quota when there is one (a 1-GPU box gets 16 of the host's cores),
     else the affinity mask."""
@@ -88,6 +93,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--action-ring", type=int, default=0, help="distinct pre-generated action blocks (0: one per step)")
+    ap.add_argument("--chunk", type=int, default=2000, help="max steps per sg_rollout_device call / rollout buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time a per-step RCCL gather of (obs,reward,done) to rank 0")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -123,9 +129,11 @@ def main():
     D = env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
-    ring = max(1, min(args.action_ring if args.action_ring > 0 else max(K, W), max(K, W)))
+    # rollout buffers hold at most `chunk` steps (2 000 steps of 65 536 envs = 7.9 GB of observations); longer runs reuse them
+    chunk = max(1, min(max(K, W, 1), args.chunk, max(1, int(24e9 // (B * (obs_dim_of(args.env) * 4 + 14))))))
+    ring = max(1, min(args.action_ring if args.action_ring > 0 else chunk, chunk))
     actions = torch.rand((ring, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-    nbuf = max(K, W, 1)
+    nbuf = chunk
     # rollout buffers in HBM (3.9 GB of observations at K=1000, B=65536, D=15)
     act_seq = actions.repeat((nbuf + ring - 1) // ring, 1, 1)[:nbuf].contiguous()
     obs = torch.empty((nbuf, B, D), device=dev, dtype=torch.float32)
@@ -142,9 +150,16 @@ def main():
                 dist.barrier(device_ids=[dev_index])
             torch.cuda.synchronize(dev)
 
+    def run_steps(n):
+        """n steps as ceil(n / chunk) sg_rollout_device calls into the (reused) rollout buffers; returns #finished episodes"""
+        left = n
+        while left > 0:
+            k = min(left, chunk)
+            env.rollout_torch(act_seq[:k], obs[:k], rew[:k], done[:k], trunc[:k])
+            left -= k
+
     env.reset_torch()
-    if W > 0:
-        env.rollout_torch(act_seq[:W], obs[:W], rew[:W], done[:W], trunc[:W])
+    run_steps(W)
     sync_all()
 
     # ---- timed region: exactly K steps, no instrumentation; one HIP event pair on the launch stream brackets it
@@ -153,7 +168,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream rollout_torch launches on
-    env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+    run_steps(K)
     ev1.record()
     sync_all()
     dt = time.perf_counter() - t0
@@ -165,7 +180,7 @@ def main():
     env.set_unfused_rollout(True)
     sync_all()
     t_u = time.perf_counter()
-    env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+    run_steps(K)
     sync_all()
     dt_unfused = time.perf_counter() - t_u
     env.set_unfused_rollout(False)
@@ -175,7 +190,7 @@ def main():
         env.set_profiling(True)
         sync_all()
         t1 = time.perf_counter()
-        env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+        run_steps(K)
         sync_all()
         dt_events = time.perf_counter() - t1
         launches, kern_ms, kmin, kmax = env.get_profile()
@@ -188,15 +203,17 @@ def main():
         sync_all()
         t2 = time.perf_counter()
         for t in range(K):
-            env.rollout_torch(act_seq[t:t + 1], obs[t:t + 1], rew[t:t + 1], done[t:t + 1], trunc[t:t + 1])
-            packed[:, :D] = obs[t]; packed[:, D] = rew[t]; packed[:, D + 1] = done[t].float()
+            j = t % chunk
+            env.rollout_torch(act_seq[j:j + 1], obs[j:j + 1], rew[j:j + 1], done[j:j + 1], trunc[j:j + 1])
+            packed[:, :D] = obs[j]; packed[:, D] = rew[j]; packed[:, D + 1] = done[j].float()
             dist.gather(packed, bufs, dst=0)
         sync_all()
         gather_ms = (time.perf_counter() - t2) * 1e3 / K
 
     red_dev = torch.device("cpu") if rehearse else dev
     stats = torch.tensor([dt, dt_unfused, dt_events or 0.0], device=red_dev, dtype=torch.float64)
-    n_done = done[:K].sum(dtype=torch.float64).reshape(1).to(red_dev)
+    k_last = K - (K - 1) // chunk * chunk  # steps in the last chunk, whose outputs are still in the buffers
+    n_done = (done[:k_last].sum(dtype=torch.float64) * (K / k_last)).reshape(1).to(red_dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(n_done, op=dist.ReduceOp.SUM)
@@ -211,21 +228,21 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, batch={B} per GPU, i.i.d. U(-1,1) actions resident in HBM "
                                    f"({ring} distinct blocks), auto-reset on (termination or 500-step truncation), "
-                                   f"the {K} steps in one sg_rollout_device call (Goal ids: one K-step kernel "
-                                   f"launch, env state in registers), outputs to a [steps, B, ...] rollout buffer in HBM",
+                                   f"the {K} steps in {-(-K // chunk)} sg_rollout_device call(s) (one K-step kernel "
+                                   f"launch each, env state in registers), outputs to a [steps, B, ...] rollout buffer in HBM",
                        "env_id": args.env, "batch_per_gpu": B, "global_batch": world * B, "obs_dim": D,
                        "parallelism": f"env-sharded x{world}, no data-path collective",
                        "episodes_finished_per_step": float(n_done.item()) / K},
         }
         if timing and launches:
             avg_us = kern_ms * 1e3 / launches
-            steps_per_launch = K // launches
+            steps_per_launch = K / launches
             achieved = steps_per_launch * B * bytes_per / (avg_us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.env, B, steps_per_launch),
                                "kernel": ("goal_rollout_kernel<3>" if steps_per_launch > 1 else "goal_step_kernel<3>")
-                               if args.env == "GoalContinuous3P-v0" else "step kernel",
-                               "env_steps_per_launch": steps_per_launch * B,
+                               if args.env == "GoalContinuous3P-v0" else "rollout kernel",
+                               "env_steps_per_launch": steps_per_launch * B, "steps_per_launch": steps_per_launch,
                                "kernel_avg_us": avg_us, "kernel_min_us": kmin * 1e3, "kernel_max_us": kmax * 1e3,
                                "launches": launches, "timing": "hipExtLaunchKernelGGL start/stop events on each of the "
                                f"{launches} dispatches of a second, identical {K}-step pass",
