@@ -44,6 +44,10 @@ typedef struct sg_config {
     int32_t max_episode_steps; /* 0 -> the id's registered value (500): gym TimeLimit, __init__.py:29 */
     int32_t auto_reset;        /* 1: finished envs restart inside step (VectorEnv semantics); 0: they keep
                                   their terminal state, like a bare reference env */
+    int32_t steering;          /* 0: Steering.velocity, what every registered id passes (ship_steering=1, __init__.py:32);
+                                  1: Steering.acceleration (ship_steering=0, the constructor default of GoalEnv / KeplerEnv:
+                                  goal.py:27, kepler.py:198): omega is integrated, the thruster is a torque
+                                  (dynamic_model.py:138-141,160-161) and the angular-velocity event (:210-212) is live */
 } sg_config;
 
 /* GoalContinuousEnv(**kwargs) / KeplerContinuousEnv(**kwargs) construction (goal.py:18-72,

@@ -37,6 +37,7 @@ class Params(C.Structure):
         ("numerator_C", C.c_double), ("rad_penalty_C", C.c_double), ("act_penalty_C", C.c_double),
         ("tiling_rows", C.c_int32), ("tiling_cols", C.c_int32), ("tiling_a", C.c_double),
         ("max_episode_steps", C.c_int32), ("randomize_orbit", C.c_int32), ("discrete_actions", C.c_int32),
+        ("steering_acceleration", C.c_int32), ("moi", C.c_double), ("max_thruster_force", C.c_double),
     ]
 
 
@@ -66,7 +67,7 @@ def _p(a, t):
 class Oracle:
     """fp64 CPU restatement for one registered env id."""
 
-    def __init__(self, env_id, threads=1):
+    def __init__(self, env_id, threads=1, steering_acceleration=False):
         self.lib = C.CDLL(build())
         self.env_id = env_id
         self.threads = int(threads)
@@ -74,6 +75,7 @@ class Oracle:
         self.lib.sgo_params_for_id.argtypes = [C.c_char_p, C.POINTER(Params)]
         if self.lib.sgo_params_for_id(env_id.encode(), C.byref(self.params)) != 0:
             raise ValueError(f"unknown env id {env_id!r}")
+        self.params.steering_acceleration = int(bool(steering_acceleration))  # Steering.acceleration (ship_steering=0)
         self.lib.sgo_obs_dim.argtypes = [C.POINTER(Params)]
         self.obs_dim = self.lib.sgo_obs_dim(C.byref(self.params))
         self.n_planets = self.params.n_planets

@@ -65,6 +65,7 @@ static void goal_params(int n_planets, sgo_params *p) {
     p->goal_sparse_reward = 5.0;
     p->distance_fctr = 100.0;              /* goal.py:16 */
     p->max_episode_steps = 500;            /* __init__.py:29 */
+    p->moi = 0.01; p->max_thruster_force = 0.05; /* __init__.py:33, goal.py:46 */
 }
 
 static void kepler_params(double a, double ecc, double angle, int randomize, sgo_params *p) {
@@ -82,6 +83,7 @@ static void kepler_params(double a, double ecc, double angle, int randomize, sgo
     p->numerator_C = 0.01; p->rad_penalty_C = 2.0; p->act_penalty_C = 0.5; /* __init__.py:86-88 */
     p->max_episode_steps = 500;
     p->randomize_orbit = randomize;
+    p->moi = 0.01; p->max_thruster_force = 0.05; /* __init__.py:74, kepler.py:208 */
 }
 
 int sgo_params_for_id(const char *id, sgo_params *out) {
@@ -120,6 +122,7 @@ typedef struct {
     const double *planets; /* [n][2] */
     double engine_force_scalar; /* float32(engine * max_engine_force) widened (numpy>=2, NEP 50) */
     double omega_cmd;           /* float32(thruster * 5.0) widened: dynamic_model.py:140 */
+    double torque;              /* thruster * max_thruster_force: dynamic_model.py:175 */
     int nfev;
 } rhs_ctx;
 
@@ -145,9 +148,10 @@ static void rhs(rhs_ctx *c, double t, double *y, double *f) {
         fy += diry * scalar;
     }
     double ax = fx / p->ship_mass, ay = fy / p->ship_mass;
-    y[5] = c->omega_cmd; /* Steering.velocity, dynamic_model.py:138-141 */
+    if (!p->steering_acceleration) y[5] = c->omega_cmd; /* Steering.velocity, dynamic_model.py:138-141 */
     f[0] = y[3]; f[1] = y[4]; f[2] = y[5];
-    f[3] = ax;   f[4] = ay;   f[5] = 0.0; /* dynamic_model.py:162-163 */
+    f[3] = ax;   f[4] = ay;
+    f[5] = p->steering_acceleration ? c->torque / p->moi : 0.0; /* dynamic_model.py:160-163 */
 }
 
 /* ======================================================================================
@@ -300,10 +304,16 @@ int sgo_make_step(const sgo_params *p, const double *planets, double *state, con
 
 int sgo_make_step_forces(const sgo_params *p, const double *planets, double *state, double engine_force_scalar,
                          double omega_cmd, sgo_diag *diag) {
+    return sgo_make_step_full(p, planets, state, engine_force_scalar, omega_cmd, 0.0, diag);
+}
+
+int sgo_make_step_full(const sgo_params *p, const double *planets, double *state, double engine_force_scalar,
+                       double omega_cmd, double torque, sgo_diag *diag) {
     rhs_ctx c;
     c.p = p; c.planets = planets; c.nfev = 0;
     c.engine_force_scalar = engine_force_scalar;
     c.omega_cmd = omega_cmd;
+    c.torque = torque;
 
     const double t0 = 0.0, t_bound = p->step_size;
     double t = t0, y[NEQ], f[NEQ];
@@ -532,7 +542,7 @@ double sgo_kepler_reward_act(const sgo_params *p, const double *s1, double act_t
  * ====================================================================================== */
 void sgo_env_step(const sgo_params *p, const double *planets, const double *goal, double *state,
                   const void *raw_action, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit, sgo_diag *diag) {
-    double efs, omega, act_term;
+    double efs, omega, act_term, torque;
     if (p->discrete_actions) {
         /* DiscreteSpaceshipEnv._translate_raw_action (spaceship_env.py:189-202): python floats -> float64 arithmetic */
         static const double table[6][2] = {{0, 0}, {1, 0}, {0, -1}, {0, 1}, {1, -1}, {1, 1}};
@@ -541,6 +551,7 @@ void sgo_env_step(const sgo_params *p, const double *planets, const double *goal
         const double engine = table[k][0], thruster = table[k][1];
         efs = engine * p->max_engine_force;   /* dynamic_model.py:171 */
         omega = thruster * 5.0;               /* dynamic_model.py:140 */
+        torque = thruster * p->max_thruster_force; /* dynamic_model.py:175 */
         act_term = p->act_penalty_C * sqrt(engine * engine + thruster * thruster); /* kepler.py:138,143 in float64 */
     } else {
         /* ContinuousSpaceshipEnv._translate_raw_action (spaceship_env.py:210-214), float32 arithmetic */
@@ -548,12 +559,13 @@ void sgo_env_step(const sgo_params *p, const double *planets, const double *goal
         float action[2] = {(raw[0] + 1.0f) / 2.0f, raw[1]};
         efs = (double)(float)(action[0] * (float)p->max_engine_force);
         omega = (double)(float)(action[1] * 5.0f);
+        torque = (double)(float)(action[1] * (float)p->max_thruster_force); /* float32 product, like engine_force_scalar */
         act_term = (double)((float)p->act_penalty_C * sqrtf(action[0] * action[0] + action[1] * action[1]));
     }
     double last_xy[2] = {state[0], state[1]}; /* spaceship_env.py:74 */
     static const double origin[2 * SGO_MAX_PLANETS] = {0};
     const double *pl = (p->family == SGO_FAMILY_GOAL) ? planets : origin; /* kepler.py:204-206: both at (0,0) */
-    *done = (uint8_t)sgo_make_step_forces(p, pl, state, efs, omega, diag);
+    *done = (uint8_t)sgo_make_step_full(p, pl, state, efs, omega, torque, diag);
     int hit = 0;
     if (p->family == SGO_FAMILY_GOAL) {
         sgo_make_observation(p, state, pl, goal, obs);

@@ -47,6 +47,9 @@ typedef struct sgo_params {
     int32_t max_episode_steps; /* gym TimeLimit, gym_space/__init__.py:29,45,61,82 */
     int32_t randomize_orbit;   /* KeplerRandomOrbits-v0 */
     int32_t discrete_actions;  /* DiscreteSpaceshipEnv (spaceship_env.py:183-202): actions are int32 indices 0..5 */
+    int32_t steering_acceleration; /* 1: Steering.acceleration (ship_steering=0, the classes' constructor default; no registered
+                                      id): omega is integrated, the thruster is a torque (dynamic_model.py:138-141,160-161) */
+    double moi, max_thruster_force; /* ship_moi 0.01 (gym_space/__init__.py:33), 0.05 (goal.py:46, kepler.py:208) */
 } sgo_params;
 
 typedef struct sgo_diag {
@@ -68,6 +71,9 @@ int sgo_make_step(const sgo_params *p, const double *planets_xy, double *state, 
  * float64 for the discrete ones): engine_force_scalar (dynamic_model.py:171) and omega (dynamic_model.py:140). */
 int sgo_make_step_forces(const sgo_params *p, const double *planets_xy, double *state, double engine_force_scalar,
                          double omega_cmd, sgo_diag *diag);
+/* General form: `torque` = thruster_action * max_thruster_force (dynamic_model.py:175), used when steering_acceleration. */
+int sgo_make_step_full(const sgo_params *p, const double *planets_xy, double *state, double engine_force_scalar,
+                       double omega_cmd, double torque, sgo_diag *diag);
 
 /* spaceship_env.py:113-131 (+ kepler.py:172-187). */
 void sgo_make_observation(const sgo_params *p, const double *state, const double *planets_xy,

@@ -11,7 +11,8 @@ _lib = None
 
 class SgConfig(C.Structure):
     _fields_ = [("env_id", C.c_char * 64), ("num_envs", C.c_int64), ("seed", C.c_uint64),
-                ("env_index_base", C.c_uint32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32)]
+                ("env_index_base", C.c_uint32), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
+                ("steering", C.c_int32)]
 
 
 class NativeError(RuntimeError):

@@ -22,11 +22,16 @@ typedef struct SgDev {
     uint32_t seed_lo, seed_hi;
     int32_t randomize_orbit;    /* KeplerRandomOrbits-v0, kepler.py:257-259 */
     int32_t discrete_actions;   /* DiscreteSpaceshipEnv (spaceship_env.py:183-202): actions are int32 indices 0..5 */
+    int32_t steering_acceleration; /* 1: Steering.acceleration (ship_steering=0: constructor default of the reference classes, used
+                                      by no registered id): omega is a state, thruster = torque (dynamic_model.py:138-141,160-161) */
 
     float h;                    /* step_size 0.07: goal.py:66, gym_space/__init__.py:76 */
     float half_world;           /* world_size / 2: goal.py:10 (3.0), kepler.py:216 (6.0) */
     float two_over_world;       /* lidar scale, spaceship_env.py:139 */
     float max_engine_force;     /* 0.4, gym_space/__init__.py:38 */
+    float max_thruster_force;   /* 0.05: goal.py:46, kepler.py:208 */
+    float inv_moi;              /* 1 / ship_moi = 100: gym_space/__init__.py:33 */
+    float omega_limit;          /* max_abs_vel_angle = 6: goal.py:67, kepler.py:217 (event dynamic_model.py:210-212) */
     float gm;                   /* G * m_ship * m_planet: helpers.py:19,34; goal.py:14,43; kepler.py:204 */
     float planet_r;             /* hexagonal_tiling.py:45-47 / kepler.py:17 */
     float border_r;             /* kepler.py:18 */

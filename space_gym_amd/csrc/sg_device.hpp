@@ -137,19 +137,20 @@ struct StepResult {
     float dX, dY;    // the same rounded to fp32
     float vx, vy;
     float t;         // time actually advanced: step_size, or the event time
+    float dth, om;   // heading advance theta(t) - theta0 and angular velocity at t
     int done;        // a terminal event fired (dynamic_model.py:124)
     int event;       // circle index, NC = world_max, NC + 1 = world_min
     int n_rk;        // accepted RK45 steps (diagnostics)
 };
 
 // RHS acceleration at displacement (X, Y) from the start position and time t since the step started:
-// thrust -(cos, sin)(theta0 + omega t) * F  (dynamic_model.py:168-176) + sum of planet pulls (helpers.py:22-35).
+// thrust -(cos, sin)(theta0 + delta) * F  (dynamic_model.py:168-176) + sum of planet pulls (helpers.py:22-35).
 // cqx/cqy are circle centres relative to the start position; the first NG circles gravitate.
 template <int NC, int NG>
-SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float F, float C0, float S0, float om,
-                 float t, float X, float Y, float &ax, float &ay) {
+SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float F, float C0, float S0, float delta,
+                 float X, float Y, float &ax, float &ay) {
     float sd, cd;
-    sincos_poly(om * t, sd, cd);  // |omega t| <= 5 * 0.07
+    sincos_poly(delta, sd, cd);  // heading advance since the step started: |delta| <= 6 * 0.07 + 2.5 * 0.07^2
     float c = fmaf(C0, cd, -S0 * sd), s = fmaf(S0, cd, C0 * sd);
     ax = -c * F;
     ay = -s * F;
@@ -174,10 +175,11 @@ SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float
 //   The angular-velocity event (:210-212, limit 6) cannot fire: |omega| = |5 a1| <= 5 for actions in [-1, 1].
 enum : int { kRkContinue = 0, kRkFinished = 1, kRkEvent = 2 };
 
-template <int NC, int NG, bool WALLS>
+// ACCEL selects Steering.acceleration at compile time: the velocity-steering kernels (every registered id) carry none of it.
+template <int NC, int NG, bool WALLS, bool ACCEL = false>
 struct Integrator {
     // constants of the env-step
-    float t_end, half_world, gm, F, om, x0, y0, C0, S0;
+    float t_end, half_world, gm, F, om, alpha, w_limit, x0, y0, C0, S0;  // om: omega at t = 0; alpha: d omega / dt
     float cax[NC], cay[NC], cR[NC], cqx[NC], cqy[NC];
     double cRd[NC];
     float wxp, wyp, wxm, wym;
@@ -188,11 +190,18 @@ struct Integrator {
     bool rejected;
     int n_rk, attempts;
 
-    SG_MFN void begin(float h_total, float half_world_, float gm_, float F_, float om_, float x0_, float y0_, float th0,
-                      float vx0, float vy0, const float (&cax_)[NC], const float (&cay_)[NC], const float (&cR_)[NC],
-                      const double (&cRd_)[NC]) {
+    // heading advance since t = 0: omega is constant (Steering.velocity) or linear in t (Steering.acceleration), so theta(t)
+    // is known in closed form; RK45 integrates such polynomials exactly and its error estimate for them is 0.
+    SG_MFN float phase(float tt) const { return ACCEL ? fmaf(om, tt, 0.5f * alpha * tt * tt) : om * tt; }
+
+    // Steering.velocity: om_ = 5 a1 (the RHS overwrites omega, dynamic_model.py:138-141), alpha_ = 0.
+    // Steering.acceleration: om_ = the state's omega, alpha_ = a1 * max_thruster_force / moi (dynamic_model.py:160-161,175).
+    SG_MFN void begin(float h_total, float half_world_, float gm_, float F_, float om_, float alpha_, float w_limit_,
+                      float x0_, float y0_, float th0, float vx0, float vy0, const float (&cax_)[NC],
+                      const float (&cay_)[NC], const float (&cR_)[NC], const double (&cRd_)[NC]) {
         SG_STAMP(8);
-        half_world = half_world_; gm = gm_; F = F_; om = om_; x0 = x0_; y0 = y0_;
+        half_world = half_world_; gm = gm_; F = F_; om = om_; alpha = ACCEL ? alpha_ : 0.0f; w_limit = w_limit_;
+        x0 = x0_; y0 = y0_;
 #pragma unroll
         for (int k = 0; k < NC; k++) { cax[k] = cax_[k]; cay[k] = cay_[k]; cR[k] = cR_[k]; cRd[k] = cRd_[k]; }
         sincos_acc(th0, S0, C0);
@@ -205,7 +214,7 @@ struct Integrator {
 
         // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
         k0[0] = vx; k0[1] = vy;
-        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
+        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
         {
             // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega)
             float sx = fmaf(fabsf(x0), kRtol, kAtol), sy = fmaf(fabsf(y0), kRtol, kAtol);
@@ -214,16 +223,18 @@ struct Integrator {
             float isx = rcp(sx), isy = rcp(sy), isth = rcp(sth), isom = rcp(som), isvx = rcp(svx), isvy = rcp(svy);
             float a0 = x0 * isx, a1 = y0 * isy, a2 = th0 * isth, a3 = vx * isvx, a4 = vy * isvy, a5 = om * isom;
             float d0 = fsqrt((a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5) * (1.0f / 6));
-            // f0 = (vx, vy, omega, ax, ay, 0)
-            float b0 = vx * isx, b1 = vy * isy, b2 = om * isth, b3 = k0[2] * isvx, b4 = k0[3] * isvy;
-            float d1 = fsqrt((b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4) * (1.0f / 6));
+            // f0 = (vx, vy, omega, ax, ay, alpha)
+            float b0 = vx * isx, b1 = vy * isy, b2 = om * isth, b3 = k0[2] * isvx, b4 = k0[3] * isvy, b5 = ACCEL ? alpha * isom : 0.0f;
+            float d1 = fsqrt((b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4 + b5 * b5) * (1.0f / 6));
             float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);
             h0 = fminf(h0, t_end);
             // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)
             float ax1, ay1;
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, h0, h0 * vx, h0 * vy, ax1, ay1);
-            float e0 = h0 * k0[2] * isx, e1 = h0 * k0[3] * isy, e3 = (ax1 - k0[2]) * isvx, e4 = (ay1 - k0[3]) * isvy;
-            float d2 = fsqrt((e0 * e0 + e1 * e1 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
+            // (Euler probe: theta1 = theta0 + h0 omega, omega1 = omega + h0 alpha)
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, h0 * om, h0 * vx, h0 * vy, ax1, ay1);
+            float e0 = h0 * k0[2] * isx, e1 = h0 * k0[3] * isy, e2 = ACCEL ? h0 * alpha * isth : 0.0f, e3 = (ax1 - k0[2]) * isvx,
+                  e4 = (ay1 - k0[3]) * isvy;
+            float d2 = fsqrt((e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
             float dm = fmaxf(d1, d2);
             float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
                                                        : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
@@ -255,28 +266,28 @@ struct Integrator {
         {
             float dvx = A21 * k0[2], dvy = A21 * k0[3];
             k1[0] = fmaf(h, dvx, vx); k1[1] = fmaf(h, dvy, vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C2, h, t), fmaf(h, A21 * k0[0], X), fmaf(h, A21 * k0[1], Y),
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C2, h, t)), fmaf(h, A21 * k0[0], X), fmaf(h, A21 * k0[1], Y),
                           k1[2], k1[3]);
         }
         {
             float s0 = fmaf(A32, k1[0], A31 * k0[0]), s1 = fmaf(A32, k1[1], A31 * k0[1]);
             float s2 = fmaf(A32, k1[2], A31 * k0[2]), s3 = fmaf(A32, k1[3], A31 * k0[3]);
             k2[0] = fmaf(h, s2, vx); k2[1] = fmaf(h, s3, vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C3, h, t), fmaf(h, s0, X), fmaf(h, s1, Y), k2[2], k2[3]);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C3, h, t)), fmaf(h, s0, X), fmaf(h, s1, Y), k2[2], k2[3]);
         }
         {
             float s[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) s[i] = fmaf(A43, k2[i], fmaf(A42, k1[i], A41 * k0[i]));
             k3[0] = fmaf(h, s[2], vx); k3[1] = fmaf(h, s[3], vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C4, h, t), fmaf(h, s[0], X), fmaf(h, s[1], Y), k3[2], k3[3]);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C4, h, t)), fmaf(h, s[0], X), fmaf(h, s[1], Y), k3[2], k3[3]);
         }
         {
             float s[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) s[i] = fmaf(A54, k3[i], fmaf(A53, k2[i], fmaf(A52, k1[i], A51 * k0[i])));
             k4[0] = fmaf(h, s[2], vx); k4[1] = fmaf(h, s[3], vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, fmaf(C5, h, t), fmaf(h, s[0], X), fmaf(h, s[1], Y), k4[2], k4[3]);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C5, h, t)), fmaf(h, s[0], X), fmaf(h, s[1], Y), k4[2], k4[3]);
         }
         {
             float s[4];
@@ -284,7 +295,7 @@ struct Integrator {
             for (int i = 0; i < 4; i++)
                 s[i] = fmaf(A65, k4[i], fmaf(A64, k3[i], fmaf(A63, k2[i], fmaf(A62, k1[i], A61 * k0[i]))));
             k5[0] = fmaf(h, s[2], vx); k5[1] = fmaf(h, s[3], vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, t + h, fmaf(h, s[0], X), fmaf(h, s[1], Y), k5[2], k5[3]);
+            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(t + h), fmaf(h, s[0], X), fmaf(h, s[1], Y), k5[2], k5[3]);
         }
         float inc[4];  // y_new - y = h * sum_j B_j K_j
 #pragma unroll
@@ -295,7 +306,7 @@ struct Integrator {
         const double Ydn = Yd + ((double)h * (double)vy + (double)(hh * fmaf(BETA5, k4[3], fmaf(BETA4, k3[3], fmaf(BETA3, k2[3], BETA1 * k0[3])))));
         const float Xn = (float)Xdn, Yn = (float)Ydn, vxn = vx + inc[2], vyn = vy + inc[3];
         k6[0] = vxn; k6[1] = vyn;
-        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, om, t + h, Xn, Yn, k6[2], k6[3]);  // f_new (FSAL)
+        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(t + h), Xn, Yn, k6[2], k6[3]);  // f_new (FSAL)
 
         // error norm over six components; theta and omega contribute exactly zero (sum E = 0, d omega/dt = 0)
         float err2 = 0.0f;
@@ -335,6 +346,21 @@ struct Integrator {
         for (int k = 0; k < NC + (WALLS ? 2 : 0); k++)
             if ((g[k] <= 0.0f && gn[k] >= 0.0f) || (g[k] >= 0.0f && gn[k] <= 0.0f)) mask |= 1u << k;
 
+        // angular-velocity event max_abs_vel_angle - |omega| (dynamic_model.py:210-212): only live with Steering.acceleration
+        // (|5 a1| <= 5 otherwise); omega is linear in t, so its root is closed-form
+        float s_w = 2.0f;
+        if constexpr (ACCEL) {
+            const float w0 = fmaf(alpha, t, om), w1 = fmaf(alpha, t_new, om);
+            const float gw0 = w_limit - fabsf(w0), gw1 = w_limit - fabsf(w1);
+            if ((gw0 <= 0.0f && gw1 >= 0.0f) || (gw0 >= 0.0f && gw1 <= 0.0f)) {
+                // crossing of +-limit between w0 and w1: the limit with the sign of whichever end is outside / larger
+                const float lim = (fabsf(w1) >= fabsf(w0) ? w1 : w0) >= 0.0f ? w_limit : -w_limit;
+                const float dw = w1 - w0;
+                s_w = (dw != 0.0f) ? fminf(fmaxf((lim - w0) * rcp(dw), 0.0f), 1.0f) : 0.0f;
+                mask |= 1u << (NC + 2);
+            }
+        }
+
         if (mask) {
             // dense output over [t, t_new]: y(s) = y_old + h s (K0 + s (Q1 + s (Q2 + s Q3))), s in [0, 1]
             float q1[4], q2[4], q3[4];
@@ -357,7 +383,7 @@ struct Integrator {
             int best_k = -1, best_comp = 0;
             float bax = 0.0f, bay = 0.0f;  // absolute centre of the winning circle event
             double bRd = 0.0;
-            unsigned m = mask;
+            unsigned m = mask & ((1u << (NC + 2)) - 1u);  // circle and wall events; the omega event is handled after them
             while (m) {  // usually one active event; all are terminal -> the earliest root wins (ivp.py:115-126)
                 const int k = __builtin_ctz(m);
                 m &= m - 1;
@@ -428,7 +454,7 @@ struct Integrator {
             // One Newton step on the winning component with g evaluated in fp64 from the unrounded inputs: the Goal
             // reward multiplies the terminal position by up to 1000 (goal.py:147-152), so fp32 noise in g (~1e-7)
             // would show.  The slope only needs a few digits.
-            {
+            if (best_k >= 0) {
                 const float s = best;
                 const float dx = X + disp(0, s), dy = Y + disp(1, s), ux = dispd(0, s), uy = dispd(1, s);
                 double gd;
@@ -445,6 +471,7 @@ struct Integrator {
                 }
                 if (fabsf(gp) > 1e-12f) best = fminf(fmaxf(s - (float)gd * rcp(gp), 0.0f), 1.0f);
             }
+            if (s_w < best) { best = s_w; best_k = NC + 2; }  // the omega event comes last in the reference's event order
             const float s = best;
             // leading term h s v in fp64, the O(h^2) remainder in fp32
             const double hs = (double)h * (double)s;
@@ -453,6 +480,7 @@ struct Integrator {
             o.dX = (float)o.dXd; o.dY = (float)o.dYd;
             o.vx = vx + disp(2, s); o.vy = vy + disp(3, s);
             o.t = fmaf(h, s, t);
+            o.dth = phase(o.t); o.om = ACCEL ? fmaf(alpha, o.t, om) : om;
             o.done = 1; o.event = best_k; o.n_rk = n_rk;
             return kRkEvent;
         }
@@ -468,16 +496,17 @@ struct Integrator {
 
     SG_MFN void finish(StepResult &o) const {
         o.dXd = Xd; o.dYd = Yd; o.dX = X; o.dY = Y; o.vx = vx; o.vy = vy; o.t = t;
+        o.dth = phase(t); o.om = ACCEL ? fmaf(alpha, t, om) : om;
         o.done = 0; o.event = -1; o.n_rk = n_rk;
     }
 };
 
-template <int NC, int NG, bool WALLS>
-SG_FN void make_step(float h_total, float half_world, float gm, float F, float om, float x0, float y0, float th0,
-                     float vx0, float vy0, const float (&cax)[NC], const float (&cay)[NC], const float (&cR)[NC],
-                     const double (&cRd)[NC], StepResult &o) {
-    Integrator<NC, NG, WALLS> I;
-    I.begin(h_total, half_world, gm, F, om, x0, y0, th0, vx0, vy0, cax, cay, cR, cRd);
+template <int NC, int NG, bool WALLS, bool ACCEL = false>
+SG_FN void make_step(float h_total, float half_world, float gm, float F, float om, float alpha, float w_limit, float x0,
+                     float y0, float th0, float vx0, float vy0, const float (&cax)[NC], const float (&cay)[NC],
+                     const float (&cR)[NC], const double (&cRd)[NC], StepResult &o) {
+    Integrator<NC, NG, WALLS, ACCEL> I;
+    I.begin(h_total, half_world, gm, F, om, alpha, w_limit, x0, y0, th0, vx0, vy0, cax, cay, cR, cRd);
     while (I.attempt(o) == kRkContinue) {}
 }
 
@@ -870,6 +899,14 @@ SG_FN void translate_action(float &a0, float &a1, float max_engine_force, float 
     om = a1 * 5.0f;                 // dynamic_model.py:140
 }
 
+// omega at t = 0 and its rate for the env-step: Steering.velocity pins omega = 5 a1 (dynamic_model.py:138-141);
+// Steering.acceleration keeps the state's omega and applies alpha = (a1 * max_thruster_force) / moi (:160-161,175)
+template <bool ACCEL>
+SG_FN void steering(const SgDev &c, float a1, float om_cmd, float om_state, float &om0, float &alpha) {
+    if (ACCEL) { om0 = om_state; alpha = (a1 * c.max_thruster_force) * c.inv_moi; }
+    else { om0 = om_cmd; alpha = 0.0f; }
+}
+
 // Raw action of env `idx` from the caller's action buffer: float32 [.., 2] for the continuous ids, int32 [..] for the
 // discrete ones.  DiscreteSpaceshipEnv._translate_raw_action (spaceship_env.py:189-202) maps the index to
 // (engine, thruster) in {0,1} x {-1,0,1}; it is returned as the raw pair (2 engine - 1, thruster) that
@@ -908,36 +945,37 @@ SG_FN void kepler_observe(const SgDev &c, const KeplerEnv &e, float (&obs)[10]) 
 
 // Goal: integrate -> observation (old goal) -> reward; the caller resamples the goal on a hit (goal.py:154-157).
 // Split into begin / finish around the resumable integrator so that the rollout kernel can interleave envs.
-template <int N>
-SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true> &I) {
-    float engine, F, om;
+template <int N, bool ACCEL = false>
+SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true, ACCEL> &I) {
+    float engine, F, om, om0, alpha;
     translate_action(a0, a1, c.max_engine_force, engine, F, om);
+    steering<ACCEL>(c, a1, om, e.om, om0, alpha);
     float cR[N];
     double cRd[N];
 #pragma unroll
     for (int j = 0; j < N; j++) { cR[j] = c.planet_r; cRd[j] = c.planet_r_d; }
-    I.begin(c.h, c.half_world, c.gm, F, om, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd);
+    I.begin(c.h, c.half_world, c.gm, F, om0, alpha, c.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd);
 }
 
 template <int N>
-SG_FN void goal_env_finish(const SgDev &c, GoalEnv<N> &e, float om, const StepResult &r, float (&obs)[7 + 2 * N + 2],
+SG_FN void goal_env_finish(const SgDev &c, GoalEnv<N> &e, const StepResult &r, float (&obs)[7 + 2 * N + 2],
                            float &reward, int &done, int &hit) {
     SG_STAMP(11);
     reward = goal_reward<N>(c, e.x, e.y, r.dXd, r.dYd, e.px, e.py, e.gx, e.gy, hit);
     SG_STAMP(12);
-    e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = om;
-    e.th = wrap_two_pi(fmaf(om, r.t, e.th));
+    e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = r.om;
+    e.th = wrap_two_pi(e.th + r.dth);
     done = r.done;
     goal_observe<N>(c, e, obs);
 }
 
-template <int N>
+template <int N, bool ACCEL = false>
 SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, float (&obs)[7 + 2 * N + 2], float &reward,
                          int &done, int &hit, StepResult &r) {
-    Integrator<N, N, true> I;
-    goal_env_begin<N>(c, e, a0, a1, I);
+    Integrator<N, N, true, ACCEL> I;
+    goal_env_begin<N, ACCEL>(c, e, a0, a1, I);
     while (I.attempt(r) == kRkContinue) {}
-    goal_env_finish<N>(c, e, I.om, r, obs, reward, done, hit);
+    goal_env_finish<N>(c, e, r, obs, reward, done, hit);
 }
 
 SG_FN Orbit fixed_orbit(const SgDev &c) {
@@ -947,18 +985,21 @@ SG_FN Orbit fixed_orbit(const SgDev &c) {
     return ob;
 }
 
+template <bool ACCEL = false>
 SG_FN void kepler_env_step(const SgDev &c, const Orbit &ob, KeplerEnv &e, float a0, float a1, float (&obs)[10],
                            float &reward, int &done, StepResult &r) {
-    float engine, F, om;
+    float engine, F, om, om0, alpha;
     translate_action(a0, a1, c.max_engine_force, engine, F, om);
+    steering<ACCEL>(c, a1, om, e.om, om0, alpha);
     // planet (R = 0.2, gravitating) and the zero-mass border circle (R = 3, crossed from inside), both at the origin
     // (kepler.py:204-206).  The world_max/min walls at +-3 enclose the border circle and can never fire first.
     const float cax[2] = {0.0f, 0.0f}, cay[2] = {0.0f, 0.0f}, cR[2] = {c.planet_r, c.border_r};
     const double cRd[2] = {c.planet_r_d, (double)c.border_r};
-    make_step<2, 1, false>(c.h, c.half_world, c.gm, F, om, e.x, e.y, e.th, e.vx, e.vy, cax, cay, cR, cRd, r);
+    make_step<2, 1, false, ACCEL>(c.h, c.half_world, c.gm, F, om0, alpha, c.omega_limit, e.x, e.y, e.th, e.vx, e.vy, cax, cay,
+                                  cR, cRd, r);
     reward = kepler_reward(c, ob, e.x, e.y, r.dXd, r.dYd, r.vx, r.vy, engine, a1);
-    e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = om;
-    e.th = wrap_two_pi(fmaf(om, r.t, e.th));
+    e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = r.om;
+    e.th = wrap_two_pi(e.th + r.dth);
     done = r.done;
     kepler_observe(c, e, obs);
 }

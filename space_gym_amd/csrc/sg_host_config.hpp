@@ -33,6 +33,7 @@ inline void fill_common(SgDev &d) {
     d.h = 0.07f;                // goal.py:66; gym_space/__init__.py:76
     d.max_engine_force = 0.4f;  // gym_space/__init__.py:38; kepler.py:199
     d.omega_max = (float)(0.7 * 6.0);  // goal.py:142, kepler.py:263 with max_abs_vel_angle = 6
+    d.max_thruster_force = 0.05f; d.inv_moi = 100.0f; d.omega_limit = 6.0f;  // goal.py:46,67; __init__.py:33
 }
 
 inline void fill_goal(SgDev &d, int n_planets) {

@@ -29,8 +29,10 @@ class SpaceGymVectorEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, env_id, num_envs, device=0, seed=0, env_index_base=0, max_episode_steps=None, auto_reset=True,
-                 validate_actions=False, terminal_observation=True, copy=True):
-        """copy=False: reset()/step() return views of the engine's pinned output buffers, overwritten by the next call
+                 validate_actions=False, terminal_observation=True, copy=True, steering="velocity"):
+        """steering: "velocity" (ship_steering=1, what every registered id uses) or "acceleration" (ship_steering=0, the
+        constructor default of the reference classes: omega is a state, the thruster a torque).
+        copy=False: reset()/step() return views of the engine's pinned output buffers, overwritten by the next call
         (no per-step allocation or copy); copy=True returns fresh arrays like gym's vector envs."""
         if env_id not in ENV_SPECS:
             raise ValueError(f"unknown env id {env_id!r}; served ids: {sorted(ENV_SPECS)}")
@@ -49,7 +51,7 @@ class SpaceGymVectorEnv:
         self.want_terminal_obs = terminal_observation
         cfg = _native.SgConfig(env_id=env_id.encode(), num_envs=self.num_envs, seed=int(seed),
                                env_index_base=int(env_index_base), max_episode_steps=int(max_episode_steps or 0),
-                               auto_reset=int(bool(auto_reset)))
+                               auto_reset=int(bool(auto_reset)), steering={"velocity": 0, "acceleration": 1}[steering])
         h = C.c_void_p()
         rc = self._lib.sg_create(C.byref(cfg), self.device, C.byref(h))
         _native.check(self._lib, None, rc, "sg_create")

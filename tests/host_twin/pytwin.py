@@ -14,8 +14,9 @@ def _p(a, t):
 
 
 class Twin:
-    def __init__(self, env_id):
+    def __init__(self, env_id, steering_acceleration=False):
         self.lib = C.CDLL(_build.build())
+        self.steering_acceleration = bool(steering_acceleration)
         self.env_id = env_id.encode()
         self.obs_dim = self.lib.twin_obs_dim(self.env_id)
         assert self.obs_dim > 0
@@ -32,6 +33,7 @@ class Twin:
                    reward=np.empty(m, np.float32), done=np.empty(m, np.uint8), goal_hit=np.empty(m, np.uint8),
                    t=np.empty(m, np.float32), n_rk=np.empty(m, np.int32), event=np.empty(m, np.int32))
         f, u8, i32 = C.c_float, C.c_uint8, C.c_int32
+        self.lib.twin_set_steering_acceleration(int(self.steering_acceleration))
         rc = self.lib.twin_step(self.env_id, C.c_int64(m), _p(state, f), _p(planets, f), _p(goal, f), action.ctypes.data_as(C.c_void_p),
                                 _p(out["state1"], f), _p(out["obs"], f), _p(out["reward"], f), _p(out["done"], u8),
                                 _p(out["goal_hit"], u8), _p(out["t"], f), _p(out["n_rk"], i32), _p(out["event"], i32))

@@ -10,7 +10,11 @@
 
 using namespace sg;
 
-template <int N>
+// Steering.acceleration for the next twin_step calls (the reference's ship_steering=0; no registered id uses it)
+static int g_steering_acceleration = 0;
+extern "C" void twin_set_steering_acceleration(int on) { g_steering_acceleration = on ? 1 : 0; }
+
+template <int N, bool ACCEL>
 static void goal_steps(const SgDev &c, int64_t m, const float *state, const float *planets, const float *goal,
                        const void *action, float *state1, float *obs, float *reward, uint8_t *done, uint8_t *hit,
                        float *t_adv, int32_t *n_rk, int32_t *event) {
@@ -26,7 +30,7 @@ static void goal_steps(const SgDev &c, int64_t m, const float *state, const floa
         StepResult sr;
         float a0, a1;
         load_action(c, action, i, a0, a1);
-        goal_env_step<N>(c, e, a0, a1, o, r, dn, ht, sr);
+        goal_env_step<N, ACCEL>(c, e, a0, a1, o, r, dn, ht, sr);
         float *s1 = state1 + 6 * i;
         s1[0] = e.x; s1[1] = e.y; s1[2] = e.th; s1[3] = e.vx; s1[4] = e.vy; s1[5] = e.om;
         std::memcpy(obs + D * i, o, sizeof(o));
@@ -47,10 +51,17 @@ extern "C" int twin_step(const char *env_id, int64_t m, const float *state, cons
                          float *t_adv, int32_t *n_rk, int32_t *event) {
     SgDev c;
     if (fill_config(env_id, c)) return -1;
+    c.steering_acceleration = g_steering_acceleration;
     if (c.family == SG_FAMILY_GOAL) {
-        if (c.n_planets == 2) goal_steps<2>(c, m, state, planets, goal, action, state1, obs, reward, done, hit, t_adv, n_rk, event);
-        else if (c.n_planets == 3) goal_steps<3>(c, m, state, planets, goal, action, state1, obs, reward, done, hit, t_adv, n_rk, event);
-        else goal_steps<4>(c, m, state, planets, goal, action, state1, obs, reward, done, hit, t_adv, n_rk, event);
+#define TWIN_GOAL(NP)                                                                                                         \
+    if (g_steering_acceleration)                                                                                              \
+        goal_steps<NP, true>(c, m, state, planets, goal, action, state1, obs, reward, done, hit, t_adv, n_rk, event);          \
+    else                                                                                                                      \
+        goal_steps<NP, false>(c, m, state, planets, goal, action, state1, obs, reward, done, hit, t_adv, n_rk, event)
+        if (c.n_planets == 2) { TWIN_GOAL(2); }
+        else if (c.n_planets == 3) { TWIN_GOAL(3); }
+        else { TWIN_GOAL(4); }
+#undef TWIN_GOAL
         return 0;
     }
     for (int64_t i = 0; i < m; i++) {
@@ -69,7 +80,8 @@ extern "C" int twin_step(const char *env_id, int64_t m, const float *state, cons
         StepResult sr;
         float a0, a1;
         load_action(c, action, i, a0, a1);
-        kepler_env_step(c, ob, e, a0, a1, o, r, dn, sr);
+        if (g_steering_acceleration) kepler_env_step<true>(c, ob, e, a0, a1, o, r, dn, sr);
+        else kepler_env_step<false>(c, ob, e, a0, a1, o, r, dn, sr);
         float *s1 = state1 + 6 * i;
         s1[0] = e.x; s1[1] = e.y; s1[2] = e.th; s1[3] = e.vx; s1[4] = e.vy; s1[5] = e.om;
         std::memcpy(obs + 10 * i, o, sizeof(o));

@@ -347,3 +347,37 @@ def test_random_orbits_match_reference_golden():
     obs, rew, done, info = env.step(d["action"])
     check_against(obs, rew, done, env.get_state()["ship"], d["state1"], d["obs"], d["reward"], d["done"])
     env.close()
+
+
+@pytest.mark.parametrize("fam,env_id", [("goal3p_accel", "GoalContinuous3P-v0"), ("kepler_circle_accel", "KeplerCircleOrbit-v0")])
+def test_acceleration_steering_matches_reference_golden(fam, env_id):
+    """Steering.acceleration through sg_config.steering = 1: fixtures from the reference with ship_steering=0."""
+    from conftest import load_golden
+    d = load_golden("step_" + fam)
+    m = len(d["state0"])
+    env = make(env_id, m, seed=1, auto_reset=False, steering="acceleration")
+    env.reset()
+    is_goal = "planets" in d
+    env.set_state(ship=d["state0"], planets=d["planets"] if is_goal else None, goal=d["goal"] if is_goal else None,
+                  elapsed=np.zeros(m, np.int32))
+    obs, rew, done, info = env.step(d["action"])
+    check_against(obs, rew, done, env.get_state()["ship"], d["state1"], d["obs"], d["reward"], d["done"])
+    env.close()
+    # and the rollout kernel == step kernel in this mode too, with omega carried between steps
+    import torch
+    n, K = 4096, 150
+    a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1
+    outs = []
+    for mode in (0, 1):
+        env = make(env_id, n, seed=2, steering="acceleration")
+        env.set_unfused_rollout(mode)
+        env.reset_torch()
+        obs = torch.empty((K, n, env.obs_dim), device="cuda"); rew = torch.empty((K, n), device="cuda")
+        dn = torch.empty((K, n), dtype=torch.uint8, device="cuda"); tr = torch.empty_like(dn)
+        env.rollout_torch(a, obs, rew, dn, tr)
+        torch.cuda.synchronize()
+        outs.append((obs.cpu().numpy(), rew.cpu().numpy(), dn.cpu().numpy(), env.get_state()["ship"]))
+        env.close()
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x, y)
+    assert outs[0][2].sum() > n // 2

@@ -242,3 +242,18 @@ def test_random_orbits_match_reference_golden():
     assert np.abs(tw["state1"][:, [0, 1, 3, 4, 5]] - d["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
     assert np.abs(tw["obs"] - d["obs"]).max() <= TOL_OBS
     assert (np.abs(tw["reward"] - d["reward"]) / np.maximum(1, np.abs(d["reward"]))).max() <= TOL_REWARD_REL
+
+
+@pytest.mark.parametrize("fam,env_id", [("goal3p_accel", "GoalContinuous3P-v0"), ("kepler_circle_accel", "KeplerCircleOrbit-v0")])
+def test_acceleration_steering_matches_reference_golden(fam, env_id):
+    from conftest import load_golden
+    d = load_golden("step_" + fam)
+    r = Twin(env_id, steering_acceleration=True).step(d["state0"], d["action"], d.get("planets"), d.get("goal"))
+    term = d["done"] == 1
+    assert np.array_equal(r["done"], d["done"]) and np.array_equal(r["goal_hit"], d["goal_changed"])
+    assert np.array_equal(r["n_rk"], d["n_rk_steps"]) and np.array_equal(r["event"][term], d["event_index"][term])
+    s1 = r["state1"].astype(np.float64)
+    assert np.abs(s1[:, [0, 1, 3, 4, 5]] - d["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
+    assert circ_diff(s1[:, 2], d["state1"][:, 2]).max() <= TOL_STATE
+    assert np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
+    assert (np.abs(r["reward"] - d["reward"]) / np.maximum(1.0, np.abs(d["reward"]))).max() <= TOL_REWARD_REL

@@ -91,3 +91,17 @@ def test_oracle_matches_reference_random_orbits():
     assert np.abs(r["state1"] - d["state1"]).max() <= TOL_STATE and np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
     assert np.abs(r["reward"] - d["reward"]).max() <= TOL_REWARD
     assert d["orbit"][:, 1].std() > 0.1  # eccentricities really vary
+
+
+@pytest.mark.parametrize("fam,env_id", [("goal3p_accel", "GoalContinuous3P-v0"), ("kepler_circle_accel", "KeplerCircleOrbit-v0")])
+def test_oracle_matches_reference_acceleration_steering(fam, env_id):
+    """Steering.acceleration (ship_steering=0): omega integrated, thruster torque, live angular-velocity event."""
+    from conftest import load_golden
+    d = load_golden("step_" + fam)
+    r = Oracle(env_id, steering_acceleration=True).step(d["state0"], d["action"], d.get("planets"), d.get("goal"), with_diag=True)
+    assert np.array_equal(r["done"], d["done"]) and np.array_equal(r["goal_hit"], d["goal_changed"])
+    assert np.array_equal(r["diag"]["n_rk_steps"], d["n_rk_steps"]) and np.array_equal(r["diag"]["event_index"], d["event_index"])
+    assert np.abs(r["state1"] - d["state1"]).max() <= TOL_STATE and np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
+    assert np.abs(r["reward"] - d["reward"]).max() <= TOL_REWARD
+    n = int(d["const_n_planets"])
+    assert (d["event_index"] == n + 2).sum() >= 20  # the angular-velocity event fires in the fixtures

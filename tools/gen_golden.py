@@ -534,6 +534,42 @@ def stage_random_orbits(args):
           f"[{arrs['orbit'][:, 1].min():.3f}, {arrs['orbit'][:, 1].max():.3f}] -> {path}", flush=True)
 
 
+def stage_acceleration(args):
+    """Steering.acceleration (ship_steering=0, the constructor default of GoalEnv / KeplerEnv: goal.py:27, kepler.py:198):
+    omega is a state variable (dynamic_model.py:138-141 does not overwrite it), the thruster gives an angular acceleration
+    (:160-161) and the angular-velocity event (:210-212) is live.  No registered id uses it; fixtures use the kwargs of the
+    3-planet / circle-orbit ids with ship_steering=0."""
+    registry, envs, dynamic_model = load_env_layer()
+    rec = IvpRecorder(dynamic_model)
+    specs = {"goal3p_accel": ("GoalContinuousEnv", dict(registry["GoalContinuous3P-v0"]["kwargs"], ship_steering=0)),
+             "kepler_circle_accel": ("KeplerContinuousEnv", dict(registry["KeplerCircleOrbit-v0"]["kwargs"], ship_steering=0))}
+    for fam, (cls_name, kwargs) in specs.items():
+        rng = np.random.RandomState(sum(map(ord, fam)) * 7919 % (1 << 31))
+        with contextlib.redirect_stdout(io.StringIO()):
+            env = getattr(envs, cls_name)(**kwargs)
+        assert env.ship_params.steering.value == 0
+        rows = rollout_rows(env, rec, rng, args.rollout_steps // 2, args.keep_nonterminal // 2)
+        rows += (forced_goal_rows if is_goal(env) else forced_kepler_rows)(env, rec, rng, args.forced_each // 2)
+        # angular-velocity event: |omega| close to the limit 6 with the thruster pushing either way
+        for _ in range(args.forced_each * 2):
+            env.reset(); quantise_env(env)
+            sv = env._ship_state._state_vec.copy()
+            sv[5] = rng.choice([-1.0, 1.0]) * (6.0 - rng.uniform(0.0, 0.5))
+            inject(env, q32(sv))
+            a = rng.uniform(-1, 1, size=2).astype(np.float32)
+            row, _ = step_and_record(env, rec, a, KINDS.index("extreme_action"))
+            rows.append(row)
+        arrs = rows_to_arrays(rows, is_goal(env))
+        arrs.update(env_constants(env))
+        arrs["const_moi"] = np.asarray(env.ship_params.moi); arrs["const_max_thruster_force"] = np.asarray(env.ship_params.max_thruster_force)
+        arrs["kind_names"] = np.array(KINDS)
+        path = os.path.join(OUT, f"step_{fam}.npz")
+        np.savez_compressed(path, **arrs)
+        n_ev = int(arrs["const_n_planets"]) + 2
+        print(f"{fam}: {len(rows)} transitions, {int(arrs['done'].sum())} terminal "
+              f"({int((arrs['event_index'] == n_ev).sum())} by the angular-velocity event) -> {path}", flush=True)
+
+
 def stage_reset(args):
     registry, envs, _ = load_env_layer()
     os.makedirs(OUT, exist_ok=True)
@@ -578,14 +614,14 @@ def stage_core(_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete", "random_orbits"], default="all")
+    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete", "random_orbits", "acceleration"], default="all")
     ap.add_argument("--rollout-steps", type=int, default=20000)
     ap.add_argument("--keep-nonterminal", type=int, default=1200)
     ap.add_argument("--forced-each", type=int, default=80)
     ap.add_argument("--n-resets", type=int, default=100000)
     args = ap.parse_args()
     if args.stage == "all":
-        for st in ("env", "core", "reset", "discrete", "random_orbits"):
+        for st in ("env", "core", "reset", "discrete", "random_orbits", "acceleration"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--stage", st,
                                    "--rollout-steps", str(args.rollout_steps),
                                    "--keep-nonterminal", str(args.keep_nonterminal),
@@ -598,6 +634,8 @@ def main():
         stage_discrete(args)
     elif args.stage == "random_orbits":
         stage_random_orbits(args)
+    elif args.stage == "acceleration":
+        stage_acceleration(args)
     else:
         stage_core(args)
 
