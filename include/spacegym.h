@@ -103,6 +103,11 @@ int sg_set_unfused_rollout(sg_env *env, int32_t on);
 int sg_get_state(sg_env *env, float *ship, float *planets, float *goal, int32_t *elapsed);
 int sg_set_state(sg_env *env, const float *ship, const float *planets, const float *goal, const int32_t *elapsed);
 
+/* SpaceshipEnv.vector_field(raw_action, state_vec=None) (spaceship_env.py:96-100): the RHS of the ODE,
+ * out float32 [num_envs, 6] = (vx, vy, omega', ax, ay, angular acceleration) at each env's current planets and either its
+ * current ship state (ship == NULL) or the given one (float32 [num_envs, 6]).  Host arrays; actions as in sg_step. */
+int sg_vector_field(sg_env *env, const void *actions_host, const float *ship_host, float *out_host);
+
 /* Page-locked host memory for the arrays passed to sg_reset / sg_step (optional: any host memory works, pinned memory
  * makes the per-step copies plain DMA).  sg_host_alloc returns NULL on failure. */
 void *sg_host_alloc(size_t bytes);

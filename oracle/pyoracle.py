@@ -93,6 +93,8 @@ class Oracle:
         self.lib.sgo_vec_step.restype = None
         self.lib.sgo_env_resample_goal.argtypes = [C.POINTER(Params), C.c_uint64, C.c_uint32, es]
         self.lib.sgo_env_resample_goal.restype = None
+        self.lib.sgo_vector_field.argtypes = [C.POINTER(Params), dp, dp, C.c_void_p, dp]
+        self.lib.sgo_vector_field.restype = None
         self.lib.sgo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         self.lib.sgo_philox4x32_10.restype = None
 
@@ -129,6 +131,18 @@ class Oracle:
         if with_diag:
             out["diag"] = np.array([(d.n_rk_steps, d.nfev, d.event_index, d.t_event) for d in diag],
                                    dtype=[("n_rk_steps", "i4"), ("nfev", "i4"), ("event_index", "i4"), ("t_event", "f8")])
+        return out
+
+    def vector_field(self, state, action, planets=None):
+        """SpaceshipEnv.vector_field (spaceship_env.py:96-100) for m states: [m, 6]"""
+        state = np.ascontiguousarray(state, np.float64); m = len(state)
+        action = self._actions(action, m)
+        planets = np.ascontiguousarray(planets, np.float64).reshape(m, -1) if planets is not None else None
+        out = np.empty((m, 6))
+        stride = action.strides[0]
+        for i in range(m):
+            self.lib.sgo_vector_field(C.byref(self.params), _p(planets[i], C.c_double) if planets is not None else None,
+                                      _p(state[i], C.c_double), C.c_void_p(action.ctypes.data + i * stride), _p(out[i], C.c_double))
         return out
 
     # ---- vector env with TimeLimit + auto-reset (engine semantics, DESIGN.md)

@@ -540,8 +540,44 @@ double sgo_kepler_reward_act(const sgo_params *p, const double *s1, double act_t
 /* ======================================================================================
  * One env.step(): spaceship_env.py:68-78
  * ====================================================================================== */
+static void translate_raw(const sgo_params *p, const void *raw_action, double *efs_o, double *omega_o, double *act_term_o,
+                          double *torque_o);
+
+void sgo_vector_field(const sgo_params *p, const double *planets, const double *state, const void *raw_action, double *field) {
+    double efs, omega, act_term, torque, y[NEQ];
+    translate_raw(p, raw_action, &efs, &omega, &act_term, &torque);
+    static const double origin[2 * SGO_MAX_PLANETS] = {0};
+    rhs_ctx c;
+    c.p = p; c.planets = (p->family == SGO_FAMILY_GOAL) ? planets : origin; c.nfev = 0;
+    c.engine_force_scalar = efs; c.omega_cmd = omega; c.torque = torque;
+    memcpy(y, state, sizeof(y));
+    rhs(&c, 0.0, y, field);
+}
+
 void sgo_env_step(const sgo_params *p, const double *planets, const double *goal, double *state,
                   const void *raw_action, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit, sgo_diag *diag) {
+    double efs, omega, act_term, torque;
+    translate_raw(p, raw_action, &efs, &omega, &act_term, &torque);
+    double last_xy[2] = {state[0], state[1]}; /* spaceship_env.py:74 */
+    static const double origin[2 * SGO_MAX_PLANETS] = {0};
+    const double *pl = (p->family == SGO_FAMILY_GOAL) ? planets : origin; /* kepler.py:204-206: both at (0,0) */
+    *done = (uint8_t)sgo_make_step_full(p, pl, state, efs, omega, torque, diag);
+    int hit = 0;
+    if (p->family == SGO_FAMILY_GOAL) {
+        sgo_make_observation(p, state, pl, goal, obs);
+        *reward = sgo_goal_reward(p, state, last_xy, pl, goal, &hit);
+    } else {
+        /* goal (if given) carries the per-env orbit [angle, ecc, a] */
+        double ang = goal ? goal[0] : p->ref_orbit_angle, ecc = goal ? goal[1] : p->ref_orbit_eccentricity;
+        double a = goal ? goal[2] : p->ref_orbit_a;
+        sgo_make_observation(p, state, pl, goal, obs);
+        *reward = sgo_kepler_reward_act(p, state, act_term, a, ecc, ang);
+    }
+    *goal_hit = (uint8_t)hit;
+}
+
+static void translate_raw(const sgo_params *p, const void *raw_action, double *efs_o, double *omega_o, double *act_term_o,
+                          double *torque_o) {
     double efs, omega, act_term, torque;
     if (p->discrete_actions) {
         /* DiscreteSpaceshipEnv._translate_raw_action (spaceship_env.py:189-202): python floats -> float64 arithmetic */
@@ -562,22 +598,7 @@ void sgo_env_step(const sgo_params *p, const double *planets, const double *goal
         torque = (double)(float)(action[1] * (float)p->max_thruster_force); /* float32 product, like engine_force_scalar */
         act_term = (double)((float)p->act_penalty_C * sqrtf(action[0] * action[0] + action[1] * action[1]));
     }
-    double last_xy[2] = {state[0], state[1]}; /* spaceship_env.py:74 */
-    static const double origin[2 * SGO_MAX_PLANETS] = {0};
-    const double *pl = (p->family == SGO_FAMILY_GOAL) ? planets : origin; /* kepler.py:204-206: both at (0,0) */
-    *done = (uint8_t)sgo_make_step_full(p, pl, state, efs, omega, torque, diag);
-    int hit = 0;
-    if (p->family == SGO_FAMILY_GOAL) {
-        sgo_make_observation(p, state, pl, goal, obs);
-        *reward = sgo_goal_reward(p, state, last_xy, pl, goal, &hit);
-    } else {
-        /* goal (if given) carries the per-env orbit [angle, ecc, a] */
-        double ang = goal ? goal[0] : p->ref_orbit_angle, ecc = goal ? goal[1] : p->ref_orbit_eccentricity;
-        double a = goal ? goal[2] : p->ref_orbit_a;
-        sgo_make_observation(p, state, pl, goal, obs);
-        *reward = sgo_kepler_reward_act(p, state, act_term, a, ecc, ang);
-    }
-    *goal_hit = (uint8_t)hit;
+    *efs_o = efs; *omega_o = omega; *act_term_o = act_term; *torque_o = torque;
 }
 
 void sgo_env_step_batch(const sgo_params *p, int64_t m, const double *planets, const double *goal, double *state,

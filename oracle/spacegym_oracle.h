@@ -97,6 +97,10 @@ void sgo_env_step(const sgo_params *p, const double *planets_xy, const double *g
                   const void *raw_action, double *obs, double *reward, uint8_t *done, uint8_t *goal_hit,
                   sgo_diag *diag);
 
+/* SpaceshipEnv.vector_field (spaceship_env.py:96-100): RHS of the ODE at `state` for the raw action: [vx, vy, omega', ax, ay, alpha]
+ * where omega' is the commanded omega under Steering.velocity (the RHS overwrites it, dynamic_model.py:138-141). */
+void sgo_vector_field(const sgo_params *p, const double *planets_xy, const double *state, const void *raw_action, double *field);
+
 /* Batched form of sgo_env_step over m independent transitions (row-major arrays). threads<=1: serial. */
 void sgo_env_step_batch(const sgo_params *p, int64_t m, const double *planets_xy, const double *goal_xy,
                         double *state, const void *raw_action, double *obs, double *reward,

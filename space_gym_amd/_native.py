@@ -39,6 +39,7 @@ SYMBOLS = {
     "sg_set_unfused_rollout": (C.c_int, [_vp, C.c_int32]),
     "sg_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sg_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sg_vector_field": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sg_host_alloc": (_vp, [C.c_size_t]),
     "sg_host_free": (None, [_vp]),
     "sg_set_profiling": (C.c_int, [_vp, C.c_int32]),

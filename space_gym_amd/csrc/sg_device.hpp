@@ -978,6 +978,20 @@ SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, floa
     goal_env_finish<N>(c, e, r, obs, reward, done, hit);
 }
 
+// SpaceshipEnv.vector_field (spaceship_env.py:96-100): RHS of the ODE at a state, [vx, vy, omega', ax, ay, alpha]
+template <int NC, int NG, bool ACCEL>
+SG_FN void vector_field(const SgDev &c, float x, float y, float th, float vx, float vy, float om_state, float a0, float a1,
+                        const float (&cax)[NC], const float (&cay)[NC], float (&f)[6]) {
+    float engine, F, om, om0, alpha, S0, C0, cqx[NC], cqy[NC];
+    translate_action(a0, a1, c.max_engine_force, engine, F, om);
+    steering<ACCEL>(c, a1, om, om_state, om0, alpha);
+    sincos_acc(th, S0, C0);
+#pragma unroll
+    for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x; cqy[k] = cay[k] - y; }
+    f[0] = vx; f[1] = vy; f[2] = om0; f[5] = alpha;
+    accel<NC, NG>(cqx, cqy, c.gm, F, C0, S0, 0.0f, 0.0f, 0.0f, f[3], f[4]);
+}
+
 SG_FN Orbit fixed_orbit(const SgDev &c) {
     Orbit ob;
     ob.a = c.k_a; ob.b = c.k_b; ob.c = c.k_c; ob.ecc = c.k_ecc; ob.cosphi = c.k_cos; ob.sinphi = c.k_sin;

@@ -180,6 +180,15 @@ class SpaceGymVectorEnv:
         self._ck(self._lib.sg_set_state(self._h, self._ptr(ship), self._ptr(planets), self._ptr(goal), self._ptr(elapsed)),
                  "sg_set_state")
 
+    def vector_field(self, actions, ship=None):
+        """SpaceshipEnv.vector_field (spaceship_env.py:96-100) for every env: float32 [B, 6] = (vx, vy, omega, ax, ay, alpha),
+        at the current state or at the given `ship` states [B, 6] (planets as they are now)."""
+        a = self._check_actions(actions)
+        ship = None if ship is None else np.ascontiguousarray(ship, np.float32)
+        out = np.empty((self.num_envs, 6), np.float32)
+        self._ck(self._lib.sg_vector_field(self._h, self._ptr(a), self._ptr(ship), self._ptr(out)), "sg_vector_field")
+        return out
+
     # ------------------------------------------------------------------ torch path (device tensors, current stream)
     def _torch(self):
         import torch

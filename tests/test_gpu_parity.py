@@ -403,3 +403,20 @@ def test_integration_md_stub_runs_as_written():
     assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
     assert np.array_equal(i1["TimeLimit.truncated"], i2["TimeLimit.truncated"])
     stub.close(); ours.close()
+
+
+def test_vector_field_matches_reference():
+    """sg_vector_field against SpaceshipEnv.vector_field outputs captured from the reference."""
+    from conftest import load_golden
+    d = load_golden("vector_field")
+    m = len(d["goal3p_state"])
+    env = make("GoalContinuous3P-v0", m, seed=1)
+    env.reset()
+    env.set_state(ship=d["goal3p_state"], planets=d["goal3p_planets"])
+    assert np.abs(env.vector_field(d["goal3p_action"]) - d["goal3p_field"]).max() < 1e-6
+    assert np.abs(env.vector_field(d["goal3p_action"], ship=d["goal3p_state"]) - d["goal3p_field"]).max() < 1e-6
+    env.close()
+    env = make("KeplerEllipseEasy-v0", m, seed=1)
+    env.reset()
+    assert np.abs(env.vector_field(d["kepler_easy_action"], ship=d["kepler_easy_state"]) - d["kepler_easy_field"]).max() < 1e-6
+    env.close()

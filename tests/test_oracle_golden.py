@@ -105,3 +105,13 @@ def test_oracle_matches_reference_acceleration_steering(fam, env_id):
     assert np.abs(r["reward"] - d["reward"]).max() <= TOL_REWARD
     n = int(d["const_n_planets"])
     assert (d["event_index"] == n + 2).sum() >= 20  # the angular-velocity event fires in the fixtures
+
+
+def test_vector_field_matches_reference():
+    """SpaceshipEnv.vector_field (spaceship_env.py:96-100)."""
+    from conftest import load_golden
+    d = load_golden("vector_field")
+    f = Oracle("GoalContinuous3P-v0").vector_field(d["goal3p_state"], d["goal3p_action"], d["goal3p_planets"])
+    assert np.abs(f - d["goal3p_field"]).max() < 1e-13
+    f = Oracle("KeplerEllipseEasy-v0").vector_field(d["kepler_easy_state"], d["kepler_easy_action"])
+    assert np.abs(f - d["kepler_easy_field"]).max() < 1e-13

@@ -570,6 +570,27 @@ def stage_acceleration(args):
               f"({int((arrs['event_index'] == n_ev).sum())} by the angular-velocity event) -> {path}", flush=True)
 
 
+def stage_vector_field(args):
+    """SpaceshipEnv.vector_field(raw_action, state_vec) (spaceship_env.py:96-100): the RHS of the ODE, for model-based users."""
+    registry, envs, _ = load_env_layer()
+    out = {}
+    for fam in ("goal3p", "kepler_easy"):
+        env = make_env(registry, envs, FAMILIES[fam])
+        rng = np.random.RandomState(5)
+        rows = []
+        for _ in range(300):
+            env.reset(); quantise_env(env)
+            a = rng.uniform(-1, 1, size=2).astype(np.float32)
+            sv = env._ship_state._state_vec.copy()
+            f = env.vector_field(a, sv.copy())  # mutates its argument's omega (dynamic_model.py:138-141)
+            rows.append((sv, a, np.array([p.center_pos for p in env.planets]).reshape(-1, 2), np.array(f, dtype=np.float64)))
+        out[fam + "_state"] = np.array([r[0] for r in rows]); out[fam + "_action"] = np.array([r[1] for r in rows])
+        out[fam + "_planets"] = np.array([r[2] for r in rows]); out[fam + "_field"] = np.array([r[3] for r in rows])
+    path = os.path.join(OUT, "vector_field.npz")
+    np.savez_compressed(path, **out)
+    print("vector_field fixtures ->", path, flush=True)
+
+
 def stage_reset(args):
     registry, envs, _ = load_env_layer()
     os.makedirs(OUT, exist_ok=True)
@@ -614,14 +635,14 @@ def stage_core(_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete", "random_orbits", "acceleration"], default="all")
+    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete", "random_orbits", "acceleration", "vector_field"], default="all")
     ap.add_argument("--rollout-steps", type=int, default=20000)
     ap.add_argument("--keep-nonterminal", type=int, default=1200)
     ap.add_argument("--forced-each", type=int, default=80)
     ap.add_argument("--n-resets", type=int, default=100000)
     args = ap.parse_args()
     if args.stage == "all":
-        for st in ("env", "core", "reset", "discrete", "random_orbits", "acceleration"):
+        for st in ("env", "core", "reset", "discrete", "random_orbits", "acceleration", "vector_field"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--stage", st,
                                    "--rollout-steps", str(args.rollout_steps),
                                    "--keep-nonterminal", str(args.keep_nonterminal),
@@ -636,6 +657,8 @@ def main():
         stage_random_orbits(args)
     elif args.stage == "acceleration":
         stage_acceleration(args)
+    elif args.stage == "vector_field":
+        stage_vector_field(args)
     else:
         stage_core(args)
 
