@@ -242,9 +242,21 @@ def test_device_tensor_path_matches_host_path():
 @pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0",
                                     "KeplerRandomOrbits-v0", "GoalDiscrete3-v0", "KeplerDiscrete-v0"])
 def test_fused_rollout_equals_step_by_step(env_id):
-    """sg_rollout_device (Goal: ONE launch for K steps, state in registers, restarts handed back through shuffles) is
-    bit-identical to K launches of the step kernel: outputs of every step and the final state, through several
-    generations of episodes and goal resamples."""
+    """sg_rollout_device (ONE launch for K steps, state in registers; Goal: next episodes pre-generated into a per-lane
+    LDS queue by the one-lane reset, Kepler: restarts handed back through shuffles) is bit-identical to K launches of the
+    step kernel (8-lane cooperative restart): outputs of every step and the final state, through several generations of
+    episodes and goal resamples."""
+    _fused_vs_step_by_step(env_id)
+
+
+@pytest.mark.parametrize("depth", ["2", "3"])
+def test_fused_rollout_queue_depths(depth, monkeypatch):
+    """both depths of the episode queue (the engine picks 2 for grids above two workgroups per CU) give the same bits"""
+    monkeypatch.setenv("SPACEGYM_SPARE_DEPTH", depth)
+    _fused_vs_step_by_step("GoalContinuous4P-v0", max_episode_steps=40)
+
+
+def _fused_vs_step_by_step(env_id, max_episode_steps=120):
     import torch
     n, K = 8192, 300
     gen = torch.Generator(device="cuda").manual_seed(3)
@@ -254,7 +266,7 @@ def test_fused_rollout_equals_step_by_step(env_id):
         a = torch.rand((K, n, 2), device="cuda", generator=gen) * 2 - 1
     outs = []
     for mode in (0, 1):  # one K-step launch (default) | one launch per step
-        env = make(env_id, n, seed=21, max_episode_steps=120)
+        env = make(env_id, n, seed=21, max_episode_steps=max_episode_steps)
         env.set_unfused_rollout(mode)
         env.reset_torch()
         D = env.obs_dim
