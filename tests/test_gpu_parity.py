@@ -249,16 +249,27 @@ def test_fused_rollout_equals_step_by_step(env_id):
     _fused_vs_step_by_step(env_id)
 
 
+@pytest.mark.parametrize("kernel", ["single", "pair"])
 @pytest.mark.parametrize("depth", ["2", "3"])
-def test_fused_rollout_queue_depths(depth, monkeypatch):
-    """both depths of the episode queue (the engine picks 2 for grids above two workgroups per CU) give the same bits"""
+def test_fused_rollout_kernels_and_queue_depths(kernel, depth, monkeypatch):
+    """both rollout kernels (one wave per 64 envs | pilot + finisher wave pairs; the engine picks by grid size) and both
+    depths of the episode queue give the same bits as the step kernel, with episodes of at most 40 steps (3 % of the envs
+    restart per step)"""
+    monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", kernel)
     monkeypatch.setenv("SPACEGYM_SPARE_DEPTH", depth)
     _fused_vs_step_by_step("GoalContinuous4P-v0", max_episode_steps=40)
 
 
-def _fused_vs_step_by_step(env_id, max_episode_steps=120):
+def test_fused_rollout_restarts_every_step(monkeypatch):
+    """max_episode_steps = 1: every env restarts in every step, so the pilot wave outruns the episode queue and generates
+    its episodes itself"""
+    monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", "pair")
+    _fused_vs_step_by_step("GoalContinuous2P-v0", max_episode_steps=1, K=64, split=40)
+
+
+def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100):
     import torch
-    n, K = 8192, 300
+    n = 8192
     gen = torch.Generator(device="cuda").manual_seed(3)
     if "Discrete" in env_id:
         a = torch.randint(0, 6, (K, n), device="cuda", generator=gen, dtype=torch.int32)
@@ -272,8 +283,8 @@ def _fused_vs_step_by_step(env_id, max_episode_steps=120):
         D = env.obs_dim
         obs = torch.empty((K, n, D), device="cuda"); rew = torch.empty((K, n), device="cuda")
         done = torch.empty((K, n), dtype=torch.uint8, device="cuda"); trunc = torch.empty_like(done)
-        env.rollout_torch(a[:100], obs[:100], rew[:100], done[:100], trunc[:100])   # two calls: state survives between them
-        env.rollout_torch(a[100:], obs[100:], rew[100:], done[100:], trunc[100:])
+        env.rollout_torch(a[:split], obs[:split], rew[:split], done[:split], trunc[:split])   # two calls: state survives between them
+        env.rollout_torch(a[split:], obs[split:], rew[split:], done[split:], trunc[split:])
         torch.cuda.synchronize()
         st = env.get_state()
         outs.append((obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), trunc.cpu().numpy(), st))
