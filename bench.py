@@ -186,6 +186,7 @@ def main():
     env.set_unfused_rollout(False)
 
     launches, kern_ms, kmin, kmax, dt_events = 0, 0.0, 0.0, 0.0, None
+    kernel_name = env.rollout_kernel(min(K, chunk))
     if timing:
         env.set_profiling(True)
         sync_all()
@@ -228,8 +229,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, batch={B} per GPU, i.i.d. U(-1,1) actions resident in HBM "
                                    f"({ring} distinct blocks), auto-reset on (termination or 500-step truncation), "
-                                   f"the {K} steps in {-(-K // chunk)} sg_rollout_device call(s) (one K-step kernel "
-                                   f"launch each, env state in registers), outputs to a [steps, B, ...] rollout buffer in HBM",
+                                   f"the {K} steps in {-(-K // chunk)} sg_rollout_device call(s) (one launch of "
+                                   f"{kernel_name} each, env state in registers), outputs to a [steps, B, ...] rollout buffer in HBM",
                        "env_id": args.env, "batch_per_gpu": B, "global_batch": world * B, "obs_dim": D,
                        "parallelism": f"env-sharded x{world}, no data-path collective",
                        "episodes_finished_per_step": float(n_done.item()) / K},
@@ -240,8 +241,7 @@ def main():
             achieved = steps_per_launch * B * bytes_per / (avg_us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.env, B, steps_per_launch),
-                               "kernel": ("goal_rollout_kernel<3>" if steps_per_launch > 1 else "goal_step_kernel<3>")
-                               if args.env == "GoalContinuous3P-v0" else "rollout kernel",
+                               "kernel": kernel_name,
                                "env_steps_per_launch": steps_per_launch * B, "steps_per_launch": steps_per_launch,
                                "kernel_avg_us": avg_us, "kernel_min_us": kmin * 1e3, "kernel_max_us": kmax * 1e3,
                                "launches": launches, "timing": "hipExtLaunchKernelGGL start/stop events on each of the "

@@ -119,6 +119,10 @@ void sg_host_free(void *ptr);
 int sg_set_profiling(sg_env *env, int32_t on);
 int sg_get_profile(sg_env *env, int64_t *launches, double *total_ms, double *min_ms, double *max_ms);
 
+/* Measurement aid: name of the kernel (as rocprofv3 --kernel-trace prints it) that sg_rollout_device launches for n_steps
+ * steps on this handle; valid until the next call on the handle. */
+const char *sg_rollout_kernel(sg_env *env, int32_t n_steps);
+
 /* The HIP stream the host-buffer calls run on (hipStream_t), for callers that want to order work after it. */
 void *sg_stream(const sg_env *env);
 

@@ -45,6 +45,7 @@ SYMBOLS = {
     "sg_set_profiling": (C.c_int, [_vp, C.c_int32]),
     "sg_get_profile": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sg_stream": (_vp, [_vp]),
+    "sg_rollout_kernel": (C.c_char_p, [_vp, C.c_int32]),
     "sg_version": (C.c_char_p, []),
 }
 

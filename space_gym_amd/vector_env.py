@@ -239,6 +239,10 @@ class SpaceGymVectorEnv:
         self._ck(self._lib.sg_set_unfused_rollout(self._h, int(on)), "sg_set_unfused_rollout")
 
     # ------------------------------------------------------------------ measurement aid
+    def rollout_kernel(self, n_steps):
+        """name of the kernel rollout_torch launches for n_steps steps (as rocprofv3 prints it)"""
+        return self._lib.sg_rollout_kernel(self._h, int(n_steps)).decode()
+
     def set_profiling(self, on):
         self._ck(self._lib.sg_set_profiling(self._h, int(bool(on))), "sg_set_profiling")
 

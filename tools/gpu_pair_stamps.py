@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Diagnostic: cycles per step and phase of the pilot and finisher waves of goal_pair_rollout_kernel
+(build with -DSG_STAMPS -DSG_STAMPS_ACC_ONLY).  Run on the GPU box:
+    SPACEGYM_LIB=space_gym_amd/lib/libspacegym_hip_accstamps.so python tools/gpu_pair_stamps.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import space_gym_amd as sg  # noqa: E402
+from space_gym_amd import _native  # noqa: E402
+
+SLOTS, WAVES = 16, 4096
+PILOT = {0: "top of step (action, loop)", 1: "begin: select_initial_step, g(t0)", 2: "RK attempts + events",
+         3: "state update", 4: "wait for a ring slot", 5: "ring record + publish", 8: "TimeLimit + restart pop"}
+FIN = {0: "loop / previous step's tail", 1: "wait for the pilot", 2: "read record + release slot", 3: "reward + update + observe",
+       4: "owner stores", 5: "refill passes", 6: "restart: pop + cold stores + obs", 7: "goal resamples"}
+
+
+def main():
+    lib = _native.load()
+    lib.sg_debug_read_stamps.argtypes = [C.c_void_p, C.c_int64]
+    B, K = 65536, 500
+    env = sg.make_vec("GoalContinuous3P-v0", B, seed=0)
+    dev = torch.device("cuda", 0)
+    acts = torch.rand((K, B, 2), device=dev) * 2 - 1
+    obs = torch.empty((K, B, env.obs_dim), device=dev); rew = torch.empty((K, B), device=dev)
+    done = torch.empty((K, B), dtype=torch.uint8, device=dev); trunc = torch.empty_like(done)
+    env.reset_torch()
+    for _ in range(2):
+        env.rollout_torch(acts, obs, rew, done, trunc)
+    torch.cuda.synchronize()
+    buf = np.zeros(SLOTS * WAVES, np.uint64)
+    assert lib.sg_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), C.c_int64(buf.size)) == 0
+    st = buf.reshape(WAVES, SLOTS)[: B // 256 * 8].reshape(-1, 8, SLOTS).astype(np.float64) / K
+    pil, fin = st[:, :4].reshape(-1, SLOTS), st[:, 4:].reshape(-1, SLOTS)
+    print("pilot waves: cycles per step (mean over %d waves)" % len(pil))
+    for k, name in PILOT.items():
+        print("  %-40s %8.0f" % (name, pil[:, k].mean()))
+    print("  %-40s %8.0f" % ("total", sum(pil[:, k].mean() for k in PILOT)))
+    print("  RK attempts per step: lane 0 %.3f, wave (max over lanes) %.3f; wave-steps with a terminal event %.3f"
+          % (pil[:, 10].mean(), pil[:, 11].mean(), pil[:, 7].mean()))
+    print("  of 'RK attempts + events': cycles between the event check and its end (root block when taken) %.0f" % pil[:, 9].mean())
+    print("finisher waves: cycles per step")
+    for k, name in FIN.items():
+        print("  %-40s %8.0f" % (name, fin[:, k].mean()))
+    print("  %-40s %8.0f" % ("total", sum(fin[:, k].mean() for k in FIN)))
+
+
+if __name__ == "__main__":
+    main()
