@@ -250,6 +250,13 @@ def test_fused_rollout_equals_step_by_step(env_id):
 
 
 @pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_fused_rollout_kernels_kepler(kernel, monkeypatch):
+    """Kepler: both rollout kernels against the step kernel, per-env random orbits, episodes of at most 40 steps"""
+    monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", kernel)
+    _fused_vs_step_by_step("KeplerRandomOrbits-v0", max_episode_steps=40)
+
+
+@pytest.mark.parametrize("kernel", ["single", "pair"])
 @pytest.mark.parametrize("depth", ["2", "3"])
 def test_fused_rollout_kernels_and_queue_depths(kernel, depth, monkeypatch):
     """both rollout kernels (one wave per 64 envs | pilot + finisher wave pairs; the engine picks by grid size) and both
@@ -265,6 +272,7 @@ def test_fused_rollout_restarts_every_step(monkeypatch):
     its episodes itself"""
     monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", "pair")
     _fused_vs_step_by_step("GoalContinuous2P-v0", max_episode_steps=1, K=64, split=40)
+    _fused_vs_step_by_step("KeplerEllipseHard-v0", max_episode_steps=1, K=64, split=40)
 
 
 def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100):
