@@ -301,6 +301,36 @@ def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100):
     _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2)
 
 
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "GoalDiscrete3-v0"])
+def test_pair_step_kernel_equals_step_kernel(env_id, monkeypatch):
+    """the one-launch-per-step kernel with pilot + finisher wave pairs (next episodes generated by the one-lane reset while
+    the pilot integrates) gives the same bits as the one-wave kernel (8-lane cooperative restart): every output of every
+    step incl. terminal observations, and the final state"""
+    import torch
+    n, K = 8192, 200
+    rng = np.random.default_rng(9)
+    acts = rng.integers(0, 6, (K, n)).astype(np.int32) if "Discrete" in env_id else rng.uniform(-1, 1, (K, n, 2)).astype(np.float32)
+    outs = []
+    for kernel in ("single", "pair"):
+        monkeypatch.setenv("SPACEGYM_STEP_KERNEL", kernel)
+        env = make(env_id, n, seed=33, max_episode_steps=60)
+        o0 = env.reset()
+        rec = [o0.copy()]
+        for t in range(K):
+            obs, rew, done, info = env.step(acts[t])
+            rec += [obs.copy(), rew.copy(), done.copy(), info["TimeLimit.truncated"].copy(),
+                    np.where(done[:, None], info["terminal_observation"], 0.0)]
+        st = env.get_state()
+        outs.append((rec, st))
+        env.close()
+    (r1, s1), (r2, s2) = outs
+    assert sum(int(x.sum()) for x in r1[3::5]) > 2 * n  # restarts happened
+    for k, (x, y) in enumerate(zip(r1, r2)):
+        assert np.array_equal(x, y), f"record {k} (step {(k - 1) // 5}, field {(k - 1) % 5}) differs"
+    for k in ("ship", "goal", "elapsed", "planets"):
+        assert np.array_equal(s1[k], s2[k]), k
+
+
 def _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2):
     assert d1.sum() > 2 * n and t1.sum() > 0  # restarts by events and by truncation happened
     for name, x, y in (("done", d1, d2), ("truncated", t1, t2), ("reward", r1, r2), ("obs", o1, o2)):
