@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--action-ring", type=int, default=0, help="distinct pre-generated action blocks (0: one per step)")
+    ap.add_argument("--action-source", choices=["torch", "engine"], default="torch",
+                    help="who draws the U(-1,1) action tape: torch.rand (per-rank generator) or sg_random_actions_device")
     ap.add_argument("--chunk", type=int, default=2000, help="max steps per sg_rollout_device call / rollout buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time a per-step RCCL gather of (obs,reward,done) to rank 0")
@@ -132,7 +134,10 @@ def main():
     # rollout buffers hold at most `chunk` steps (2 000 steps of 65 536 envs = 7.9 GB of observations); longer runs reuse them
     chunk = max(1, min(max(K, W, 1), args.chunk, max(1, int(24e9 // (B * (obs_dim_of(args.env) * 4 + 14))))))
     ring = max(1, min(args.action_ring if args.action_ring > 0 else chunk, chunk))
-    actions = torch.rand((ring, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+    if args.action_source == "engine":  # sg_random_actions_device: Philox keyed by (seed, global env index, step)
+        actions = env.random_actions_torch(ring, seed=1)
+    else:
+        actions = torch.rand((ring, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
     nbuf = chunk
     # rollout buffers in HBM (3.9 GB of observations at K=1000, B=65536, D=15)
     act_seq = actions.repeat((nbuf + ring - 1) // ring, 1, 1)[:nbuf].contiguous()

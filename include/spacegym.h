@@ -94,6 +94,13 @@ int sg_rollout_device(sg_env *env, int32_t n_steps, const void *actions_dev, flo
                       uint8_t *done_dev, uint8_t *truncated_dev, void *hip_stream);
 int sg_set_unfused_rollout(sg_env *env, int32_t on);
 
+/* On-device action source for sg_rollout_device: the uniformly random policy (what the reference's README loop and the
+ * benchmark use: env.action_space.sample(), gym spaces Box / Discrete).  Fills actions_dev [n_steps, num_envs, 2] float32
+ * with i.i.d. U(-1, 1) values (discrete ids: int32 [n_steps, num_envs] uniform in 0..5).  Entry (t, i) is a function of
+ * (seed, env_index_base + i, first_step + t) only (Philox4x32-10), so it does not depend on how a job is sharded over
+ * GPUs or cut into calls.  Enqueues one kernel on the stream. */
+int sg_random_actions_device(sg_env *env, int32_t n_steps, uint64_t seed, uint64_t first_step, void *actions_dev, void *hip_stream);
+
 /* State access (the reference exposes env._ship_state._state_vec, planet.center_pos, env.goal_pos as plain
  * attributes; golden-vector injection needs the same).  Host arrays, any may be NULL to skip:
  *   ship    float32 [num_envs, 6]   x, y, theta, vx, vy, omega   (dynamic_model.py:40)

@@ -46,6 +46,7 @@ SYMBOLS = {
     "sg_get_profile": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sg_stream": (_vp, [_vp]),
     "sg_rollout_kernel": (C.c_char_p, [_vp, C.c_int32]),
+    "sg_random_actions_device": (C.c_int, [_vp, C.c_int32, C.c_uint64, C.c_uint64, _vp, _vp]),
     "sg_version": (C.c_char_p, []),
 }
 

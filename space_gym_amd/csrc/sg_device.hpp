@@ -636,7 +636,7 @@ SG_FN void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uin
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-constexpr uint32_t kStreamReset = 0u, kStreamGoal = 1u;
+constexpr uint32_t kStreamReset = 0u, kStreamGoal = 1u, kStreamAction = 2u;
 
 // Reset words (RNG): word k of an episode = component k%4 of Philox block k/4 of the reset stream, so the
 // blocks can be generated by different lanes at once (cooperative restart in sg_engine.hip) or one after the other.
@@ -872,6 +872,17 @@ SG_FN void kepler_reset(const SgDev &c, uint32_t env_global, uint32_t episode, S
     s.x = ca * dist; s.y = sa * dist;
     if (c.randomize_orbit) { ecc = u23(w[3]) * 0.7f; phi = u23(w[4]) * kTwoPi; }    // kepler.py:257-259
     kinematics_from_words(c, w[2], w[8], w[9], w[10], w[11], s);
+}
+
+// Random policy on the device (sg_random_actions_device): the actions of env `env_global` at steps 2p and 2p + 1 come from one
+// Philox block keyed by the caller's seed, counter (env, p lo, p hi, stream): a0, a1 = 2 u23(w) - 1 in (-1, 1) (exact in
+// fp32), or for the discrete ids floor(6 w / 2^32).  A function of (seed, global env index, step) only.
+SG_FN void random_action_words(uint32_t seed_lo, uint32_t seed_hi, uint32_t env_global, uint64_t step, uint32_t &w0, uint32_t &w1) {
+    uint32_t o[4];
+    const uint64_t p = step >> 1;
+    philox4x32_10(seed_lo, seed_hi, env_global, (uint32_t)p, (uint32_t)(p >> 32), kStreamAction, o);
+    w0 = (step & 1u) ? o[2] : o[0];
+    w1 = (step & 1u) ? o[3] : o[1];
 }
 
 // ------------------------------------------------------------------------------------------------

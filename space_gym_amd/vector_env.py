@@ -211,10 +211,14 @@ class SpaceGymVectorEnv:
         return obs
 
     def step_torch(self, actions, out=None, terminal_obs=None):
-        """actions: float32 CUDA tensor [B, 2].  Returns (obs, reward, done, truncated) device tensors, which are reused
-        by the next call unless `out` (a dict with the same keys) is given."""
+        """actions: float32 CUDA tensor [B, 2] (discrete ids: int32 [B]), or any device array exporting DLPack
+        (`__dlpack__`: CuPy, JAX, ...; taken zero-copy).  Returns (obs, reward, done, truncated) device tensors, which are
+        reused by the next call unless `out` (a dict with the same keys) is given; `torch.utils.dlpack.to_dlpack` /
+        `__dlpack__` hands them on to other frameworks without a copy."""
         torch, bufs = self._torch()
         o = bufs if out is None else out
+        if not isinstance(actions, torch.Tensor) and hasattr(actions, "__dlpack__"):
+            actions = torch.from_dlpack(actions)
         want = (torch.int32, (self.num_envs,)) if self.discrete else (torch.float32, (self.num_envs, 2))
         assert actions.is_cuda and actions.is_contiguous() and (actions.dtype, tuple(actions.shape)) == want, want
         rc = self._lib.sg_step_device(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(o["obs"].data_ptr()),
@@ -233,6 +237,19 @@ class SpaceGymVectorEnv:
         self._ck(rc, "sg_rollout_device")
         return obs, reward, done, trunc
 
+
+    def random_actions_torch(self, n_steps, seed=0, first_step=0, out=None):
+        """the uniformly random policy generated on the device: [n_steps, B, 2] float32 in (-1, 1) (discrete ids: int32
+        [n_steps, B] in 0..5); entry (t, i) depends only on (seed, global env index, first_step + t)."""
+        import torch
+        shape = (int(n_steps), self.num_envs) if self.discrete else (int(n_steps), self.num_envs, 2)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.int32 if self.discrete else torch.float32, device=f"cuda:{self.device}")
+        assert tuple(out.shape) == shape and out.is_contiguous()
+        rc = self._lib.sg_random_actions_device(self._h, int(n_steps), C.c_uint64(seed), C.c_uint64(first_step),
+                                                C.c_void_p(out.data_ptr()), self._stream())
+        self._ck(rc, "sg_random_actions_device")
+        return out
 
     def set_unfused_rollout(self, on):
         """rollout_torch as K launches of the step kernel instead of the fused K-step kernel (A/B, equivalence test)."""

@@ -346,6 +346,64 @@ def _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2):
         assert np.array_equal(s1["planets"], s2["planets"])
 
 
+def test_step_accepts_dlpack_actions():
+    """step_torch takes any DLPack exporter zero-copy; outputs export DLPack themselves"""
+    import torch
+
+    class Foreign:  # stands in for a CuPy / JAX device array: only the DLPack protocol
+        def __init__(self, t): self.t = t
+        def __dlpack__(self, stream=None): return self.t.__dlpack__()
+        def __dlpack_device__(self): return self.t.__dlpack_device__()
+
+    n = 2048
+    a = torch.rand((n, 2), device="cuda") * 2 - 1
+    outs = []
+    for wrap in (lambda x: x, Foreign):
+        env = make("GoalContinuous3P-v0", n, seed=4)
+        env.reset_torch()
+        obs, rew, done, trunc = env.step_torch(wrap(a))
+        torch.cuda.synchronize()
+        outs.append((obs.clone(), rew.clone()))
+        assert torch.equal(torch.from_dlpack(obs.__dlpack__()), obs)
+        env.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_device_random_policy():
+    """sg_random_actions_device: entry (t, i) is the documented function of (seed, global env index, step) -- checked against
+    the oracle's Philox --, independent of sharding and of how the steps are cut into calls; uniform on (-1, 1) / on 0..5"""
+    import torch
+    o = Oracle("GoalContinuous3P-v0")
+    n, K, seed = 4096, 64, 0x1234567890ABCDEF
+    env = make("GoalContinuous3P-v0", n, seed=1)
+    a = env.random_actions_torch(K, seed=seed).cpu().numpy()
+    assert a.shape == (K, n, 2) and a.dtype == np.float32
+    for t, i in [(0, 0), (1, 0), (2, 5), (63, 4095), (17, 1000)]:
+        w = o.philox((seed & 0xFFFFFFFF, seed >> 32), (i, t >> 1, 0, 2))
+        w0, w1 = (w[2], w[3]) if t & 1 else (w[0], w[1])
+        exp = [np.float32(2.0 * (((x >> 9) + 0.5) / 8388608.0) - 1.0) for x in (w0, w1)]
+        assert a[t, i, 0] == exp[0] and a[t, i, 1] == exp[1]
+    assert np.abs(a).max() < 1.0 and abs(a.mean()) < 5e-3 and abs(a.var() - 1 / 3) < 5e-3
+    assert abs(np.corrcoef(a[:-1].ravel(), a[1:].ravel())[0, 1]) < 5e-3
+    b = torch.cat([env.random_actions_torch(40, seed=seed), env.random_actions_torch(24, seed=seed, first_step=40)]).cpu().numpy()
+    assert np.array_equal(a, b)
+    env.close()
+    hi = make("GoalContinuous3P-v0", n // 2, seed=1, env_index_base=n // 2)
+    assert np.array_equal(hi.random_actions_torch(K, seed=seed).cpu().numpy(), a[:, n // 2:])
+    hi.close()
+    d = make("GoalDiscrete3-v0", n, seed=1)
+    k = d.random_actions_torch(K, seed=seed).cpu().numpy()
+    assert k.shape == (K, n) and k.dtype == np.int32 and k.min() == 0 and k.max() == 5
+    assert np.abs(np.bincount(k.ravel(), minlength=6) / k.size - 1 / 6).max() < 5e-3
+    obs = torch.empty((K, n, d.obs_dim), device="cuda"); rew = torch.empty((K, n), device="cuda")
+    done = torch.empty((K, n), dtype=torch.uint8, device="cuda"); trunc = torch.empty_like(done)
+    d.reset_torch()
+    d.rollout_torch(d.random_actions_torch(K, seed=seed), obs, rew, done, trunc)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    d.close()
+
+
 def test_sharding_is_invariant_to_the_split():
     """Two handles with env_index_base 0 and B/2 reproduce one handle of B envs bit for bit (RNG keyed by global index)."""
     n = 4096
