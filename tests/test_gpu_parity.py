@@ -275,7 +275,14 @@ def test_fused_rollout_restarts_every_step(monkeypatch):
     _fused_vs_step_by_step("KeplerEllipseHard-v0", max_episode_steps=1, K=64, split=40)
 
 
-def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100):
+@pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "KeplerEllipseEasy-v0"])
+def test_fused_rollout_without_auto_reset(env_id):
+    """auto_reset off: finished envs keep their terminal state (and keep being stepped from it); the wave-pair kernels then
+    solve terminal events in the pilot wave and never touch the episode queue"""
+    _fused_vs_step_by_step(env_id, K=120, split=50, auto_reset=False)
+
+
+def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100, auto_reset=True):
     import torch
     n = 8192
     gen = torch.Generator(device="cuda").manual_seed(3)
@@ -285,7 +292,7 @@ def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100):
         a = torch.rand((K, n, 2), device="cuda", generator=gen) * 2 - 1
     outs = []
     for mode in (0, 1):  # one K-step launch (default) | one launch per step
-        env = make(env_id, n, seed=21, max_episode_steps=max_episode_steps)
+        env = make(env_id, n, seed=21, max_episode_steps=max_episode_steps, auto_reset=auto_reset)
         env.set_unfused_rollout(mode)
         env.reset_torch()
         D = env.obs_dim
@@ -298,7 +305,7 @@ def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100):
         outs.append((obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), trunc.cpu().numpy(), st))
         env.close()
     (o1, r1, d1, t1, s1), (o2, r2, d2, t2, s2) = outs
-    _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2)
+    _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2, restarts=auto_reset)
 
 
 @pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "GoalDiscrete3-v0"])
@@ -331,8 +338,8 @@ def test_pair_step_kernel_equals_step_kernel(env_id, monkeypatch):
         assert np.array_equal(s1[k], s2[k]), k
 
 
-def _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2):
-    assert d1.sum() > 2 * n and t1.sum() > 0  # restarts by events and by truncation happened
+def _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2, restarts=True):
+    assert (d1.sum() > 2 * n and t1.sum() > 0) if restarts else d1.sum() > 0  # restarts by events and by truncation happened
     for name, x, y in (("done", d1, d2), ("truncated", t1, t2), ("reward", r1, r2), ("obs", o1, o2)):
         if not np.array_equal(x, y):
             bad = np.argwhere(x != y)
