@@ -14,10 +14,9 @@ import space_gym_amd as sg  # noqa: E402
 from space_gym_amd import _native  # noqa: E402
 
 SLOTS, WAVES = 16, 4096
-PILOT = {0: "top of step (action, loop)", 1: "begin: select_initial_step, g(t0)", 2: "RK attempts + events",
-         3: "state update", 4: "wait for a ring slot", 5: "ring record + publish", 8: "TimeLimit + restart pop"}
-FIN = {0: "loop / previous step's tail", 1: "wait for the pilot", 2: "read record + release slot", 3: "reward + update + observe",
-       4: "owner stores", 5: "refill passes", 6: "restart: pop + cold stores + obs", 7: "goal resamples"}
+PILOT = {0: "top of step (action, loop)", 1: "begin: select_initial_step, g(t0)", 2: "RK attempts + event roots",
+         3: "state update", 4: "wait for a ring slot", 5: "ring record + publish", 8: "TimeLimit + restart"}
+FIN = {0: "loop", 1: "wait for the pilot", 2: "everything else (reward, observation, stores, queue, resamples)"}
 
 
 def main():
@@ -41,9 +40,7 @@ def main():
     for k, name in PILOT.items():
         print("  %-40s %8.0f" % (name, pil[:, k].mean()))
     print("  %-40s %8.0f" % ("total", sum(pil[:, k].mean() for k in PILOT)))
-    print("  RK attempts per step: lane 0 %.3f, wave (max over lanes) %.3f; wave-steps with a terminal event %.3f"
-          % (pil[:, 10].mean(), pil[:, 11].mean(), pil[:, 7].mean()))
-    print("  of 'RK attempts + events': cycles between the event check and its end (root block when taken) %.0f" % pil[:, 9].mean())
+    print("  wave-steps with a terminal event %.3f" % pil[:, 7].mean())
     print("finisher waves: cycles per step")
     for k, name in FIN.items():
         print("  %-40s %8.0f" % (name, fin[:, k].mean()))
