@@ -282,9 +282,16 @@ def test_fused_rollout_without_auto_reset(env_id):
     _fused_vs_step_by_step(env_id, K=120, split=50, auto_reset=False)
 
 
-def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100, auto_reset=True):
+@pytest.mark.parametrize("n", [1, 1000])
+def test_fused_rollout_ragged_batches(n):
+    """batches that do not fill a workgroup (BASELINE's single-env plumbing case, and a last workgroup with idle lanes):
+    both rollout kernels and the pair step kernel against the one-wave step kernel"""
+    for env_id in ("GoalContinuous2P-v0", "KeplerCircleOrbit-v0"):
+        _fused_vs_step_by_step(env_id, max_episode_steps=40, n=n)
+
+
+def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100, auto_reset=True, n=8192):
     import torch
-    n = 8192
     gen = torch.Generator(device="cuda").manual_seed(3)
     if "Discrete" in env_id:
         a = torch.randint(0, 6, (K, n), device="cuda", generator=gen, dtype=torch.int32)
