@@ -8,9 +8,24 @@ import os
 import sys
 
 
+def newest(pattern):
+    f = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return f[-1:]  # a directory may hold the files of an earlier run of the same tag
+
+
 def kernel_rows(path, needle):
-    f = glob.glob(os.path.join(path, "**", "*_kernel_stats.csv"), recursive=True)
+    f = newest(os.path.join(path, "**", "*_kernel_stats.csv"))
     return [r for r in csv.DictReader(open(f[0])) if needle in r["Name"]] if f else []
+
+
+def dispatch_durations(path, needle):
+    """[(kernel, duration_us)] of every dispatch whose name contains `needle`, in launch order"""
+    f = newest(os.path.join(path, "**", "*_kernel_trace.csv"))
+    if not f:
+        return []
+    rows = [r for r in csv.DictReader(open(f[0])) if needle in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    return [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
 
 
 def short(name):
@@ -19,7 +34,7 @@ def short(name):
 
 def counters_by_kernel(path, needle):
     """{kernel: {counter: [values per dispatch, in dispatch order]}}"""
-    f = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)
+    f = newest(os.path.join(path, "**", "*_counter_collection.csv"))
     out = {}
     if not f:
         return out
@@ -38,11 +53,14 @@ def main():
     except Exception as e:  # noqa: BLE001
         print("bench.json unreadable:", e)
     print("\n## rocprofv3 --kernel-trace --stats (python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-kernel-timing)")
-    print("## (the rollout kernel is launched twice: 100 warm-up steps, then the 1000 timed steps = MaxNs; the step kernel's")
-    print("##  1000 calls are bench.py's one-launch-per-step A/B pass)")
+    print("## (rollout kernel launches, in order: bench.py's untimed pre-roll in 1000-step launches, 100 warm-up steps, then the")
+    print("##  1000 TIMED steps = the LAST rollout dispatch; the step kernel's 1000 calls are the one-launch-per-step A/B pass)")
     for r in kernel_rows(os.path.join(d, "trace"), needle):
         print({k: (short(r[k]) if k == "Name" else r[k]) for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")})
-    print("\n## PMC, separate passes; per kernel: mean per dispatch and the largest dispatch (rollout kernel: the 1000-step launch)")
+    roll = [(k, us) for k, us in dispatch_durations(os.path.join(d, "trace"), "rollout_kernel")]
+    if roll:
+        print("rollout dispatches in launch order, us:", ", ".join(f"{us:.1f}" for _, us in roll), f"  -> timed launch: {roll[-1][1]:.1f} us ({roll[-1][0]})")
+    print("\n## PMC, separate passes; per kernel: mean per dispatch and the largest dispatch (rollout kernel: a 1000-step launch)")
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         for kern, cs in counters_by_kernel(os.path.join(d, sub), needle).items():
             for k, v in cs.items():
