@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--action-ring", type=int, default=0, help="distinct pre-generated action blocks (0: one per step)")
     ap.add_argument("--action-source", choices=["torch", "engine"], default="torch",
                     help="who draws the U(-1,1) action tape: torch.rand (per-rank generator) or sg_random_actions_device")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline sample")
     ap.add_argument("--preroll", type=int, default=3000,
                     help="untimed steps run before the warm-up steps, as part of the set-up: ~13 ms of the same kernel, so that "
                          "the GPU has left its idle clocks before anything is measured (a 100-step warm-up alone is 0.4 ms; "
@@ -266,7 +267,7 @@ def main():
         if gather_ms is not None:
             out["ms_per_step_with_rccl_gather"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.env, B)
+            out["cpu_baseline"] = cpu_baseline(args.env, B, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:

@@ -553,3 +553,24 @@ def test_vector_field_matches_reference():
     env.reset()
     assert np.abs(env.vector_field(d["kepler_easy_action"], ship=d["kepler_easy_state"]) - d["kepler_easy_field"]).max() < 1e-6
     env.close()
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (tiny sizes here)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "64", "--warmup", "8", "--preroll", "16",
+                          "--batch", "4096", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["steps"] == 64 and b["warmup"] == 8 and b["n_gpus"] == 1 and b["unit"] == "env-steps/s" and b["higher_is_better"]
+    assert abs(b["value"] - 4096 * 64 / (b["ms_per_step"] * 64e-3)) / b["value"] < 1e-6
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "kernel" in r
+    c = b["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s"
