@@ -343,8 +343,8 @@ struct Integrator {
         }
         if (WALLS) { gn[NC] = fminf(wxp - Xn, wyp - Yn); gn[NC + 1] = fminf(wxm + Xn, wym + Yn); }
 #pragma unroll
-        for (int k = 0; k < NC + (WALLS ? 2 : 0); k++)
-            if ((g[k] <= 0.0f && gn[k] >= 0.0f) || (g[k] >= 0.0f && gn[k] <= 0.0f)) mask |= 1u << k;
+        for (int k = 0; k < NC + (WALLS ? 2 : 0); k++)  // sign change or a zero at either end (find_active_events, ivp.py:128-156)
+            if (g[k] * gn[k] <= 0.0f) mask |= 1u << k;   // == (g <= 0 && gn >= 0) || (g >= 0 && gn <= 0): |g| is 0 or >= 1e-8, no underflow
 
         // angular-velocity event max_abs_vel_angle - |omega| (dynamic_model.py:210-212): only live with Steering.acceleration
         // (|5 a1| <= 5 otherwise); omega is linear in t, so its root is closed-form
