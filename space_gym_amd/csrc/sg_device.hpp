@@ -226,7 +226,7 @@ struct Integrator {
             // f0 = (vx, vy, omega, ax, ay, alpha)
             float b0 = vx * isx, b1 = vy * isy, b2 = om * isth, b3 = k0[2] * isvx, b4 = k0[3] * isvy, b5 = ACCEL ? alpha * isom : 0.0f;
             float d1 = fsqrt((b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4 + b5 * b5) * (1.0f / 6));
-            float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);
+            float h0 = (fminf(d0, d1) < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);  // d0 < 1e-5 or d1 < 1e-5 (common.py:96-99)
             h0 = fminf(h0, t_end);
             // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)
             float ax1, ay1;
@@ -236,7 +236,7 @@ struct Integrator {
                   e4 = (ay1 - k0[3]) * isvy;
             float d2 = fsqrt((e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
             float dm = fmaxf(d1, d2);
-            float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
+            float h1 = (dm <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
                                                        : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
             h_abs = fminf(fminf(100.0f * h0, h1), t_end);
         }
@@ -405,8 +405,8 @@ struct Integrator {
                 float gaA, gbA, gaB = 1.0f, gbB = 1.0f;
                 if (circle) { gaA = g0; gbA = g1; }
                 else { gaA = wx - sgn * X; gbA = wx - sgn * Xn; gaB = wy - sgn * Y; gbB = wy - sgn * Yn; }
-                const bool crossA = (gaA <= 0.0f && gbA >= 0.0f) || (gaA >= 0.0f && gbA <= 0.0f);
-                const bool crossB = !circle && ((gaB <= 0.0f && gbB >= 0.0f) || (gaB >= 0.0f && gbB <= 0.0f));
+                const bool crossA = gaA * gbA <= 0.0f;  // sign change or a zero at either end (as for `mask`)
+                const bool crossB = !circle && gaB * gbB <= 0.0f;
                 float loA = 0.0f, hiA = 1.0f, loB = 0.0f, hiB = 1.0f;
                 float denA = gaA - gbA, denB = gaB - gbB;
                 float sA = (denA != 0.0f) ? fminf(fmaxf(gaA * rcp(denA), 0.0f), 1.0f) : 0.0f;
