@@ -253,8 +253,9 @@ struct Integrator {
 
     // One RK attempt.  Returns kRkContinue, or fills `o` and returns kRkFinished / kRkEvent.
     SG_MFN int attempt(StepResult &o) {
+        // (t < t_end holds on entry: begin() starts at t = 0 and the exits below leave the loop once t_end is reached or the
+        //  attempt budget is spent)
         attempts++;
-        if (!(t < t_end) || attempts > kMaxRkAttempts) { finish(o); return kRkFinished; }
         float k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
         // RungeKutta._step_impl (rk.py:111-176)
         h_abs = fmaxf(h_abs, 1e-9f);
@@ -325,6 +326,7 @@ struct Integrator {
         if (!(err < 1.0f)) {  // rejected (also for NaN): shrink and retry
             h_abs = h * fmaxf(kMinFactor, kSafety * fexp2(-0.2f * flog2(err)));
             rejected = true;
+            if (attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
             return kRkContinue;
         }
         float factor = (err == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * fexp2(-0.2f * flog2(err)));
@@ -490,7 +492,7 @@ struct Integrator {
         t = t_new; X = Xn; Y = Yn; Xd = Xdn; Yd = Ydn; vx = vxn; vy = vyn;
 #pragma unroll
         for (int i = 0; i < 4; i++) k0[i] = k6[i];
-        if (!(t < t_end)) { finish(o); return kRkFinished; }
+        if (!(t < t_end) || attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
         return kRkContinue;
     }
 
