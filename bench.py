@@ -95,11 +95,13 @@ def main():
     ap.add_argument("--action-ring", type=int, default=0, help="distinct pre-generated action blocks (0: one per step)")
     ap.add_argument("--action-source", choices=["torch", "engine"], default="torch",
                     help="who draws the U(-1,1) action tape: torch.rand (per-rank generator) or sg_random_actions_device")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed K-step region is run this many times; `value` is the first, "
+                    "the others are reported as ms_per_step_repeats / ms_per_step_median")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline sample")
-    ap.add_argument("--preroll", type=int, default=3000,
-                    help="untimed steps run before the warm-up steps, as part of the set-up: ~13 ms of the same kernel, so that "
+    ap.add_argument("--preroll", type=int, default=12000,
+                    help="untimed steps run before the warm-up steps, as part of the set-up: ~50 ms of the same kernel, so that "
                          "the GPU has left its idle clocks before anything is measured (a 100-step warm-up alone is 0.4 ms; "
-                         "measured: 4.38 us/step right after idle, 4.09 after 13 ms of work, same kernel)")
+                         "measured: 4.38 us/step right after idle, 4.09 after 13 ms, 3.55 after 50 ms of work, same kernel)")
     ap.add_argument("--chunk", type=int, default=2000, help="max steps per sg_rollout_device call / rollout buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time a per-step RCCL gather of (obs,reward,done) to rank 0")
@@ -185,6 +187,14 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     stream_ms_per_launch = ev0.elapsed_time(ev1) / K  # kernel + inter-kernel gap
+    # ---- the same K-step region repeated (SURVEY 8d asks for >= 5 repeats and their median); `value` stays the first one
+    repeats = [dt]
+    for _ in range(max(0, args.repeats - 1)):
+        sync_all()
+        tr = time.perf_counter()
+        run_steps(K)
+        sync_all()
+        repeats.append(time.perf_counter() - tr)
 
     # ---- the same K steps again with start/stop events on every dispatch (hipExtLaunchKernelGGL): the kernel's own
     # duration, as rocprofv3 --kernel-trace reports it.  Costs ~35% throughput, hence not done in the region above.
@@ -262,6 +272,8 @@ def main():
                                "algorithmic_bytes_per_env_step": bytes_per,
                                "algorithmic_bytes_per_launch": steps_per_launch * B * bytes_per}
             out["value_with_dispatch_events"] = world * B * K / dt_events
+        out["ms_per_step_repeats"] = [r * 1e3 / K for r in repeats]  # rank 0's clock
+        out["ms_per_step_median"] = sorted(out["ms_per_step_repeats"])[len(repeats) // 2]
         out["value_one_launch_per_step"] = world * B * K / dt_unfused
         out["ms_per_step_one_launch_per_step"] = dt_unfused * 1e3 / K
         if gather_ms is not None:

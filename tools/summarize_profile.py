@@ -53,13 +53,16 @@ def main():
     except Exception as e:  # noqa: BLE001
         print("bench.json unreadable:", e)
     print("\n## rocprofv3 --kernel-trace --stats (python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-kernel-timing)")
-    print("## (rollout kernel launches, in order: bench.py's untimed pre-roll in 1000-step launches, 100 warm-up steps, then the")
-    print("##  1000 TIMED steps = the LAST rollout dispatch; the step kernel's 1000 calls are the one-launch-per-step A/B pass)")
+    print("## (rollout kernel launches, in order: bench.py's untimed pre-roll in 1000-step launches, the 100 warm-up steps (the short")
+    print("##  dispatch), the 1000 TIMED steps = the dispatch right after it, then bench.py's repeats of the same region; the step")
+    print("##  kernel's 1000 calls are the one-launch-per-step A/B pass)")
     for r in kernel_rows(os.path.join(d, "trace"), needle):
         print({k: (short(r[k]) if k == "Name" else r[k]) for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")})
     roll = [(k, us) for k, us in dispatch_durations(os.path.join(d, "trace"), "rollout_kernel")]
     if roll:
-        print("rollout dispatches in launch order, us:", ", ".join(f"{us:.1f}" for _, us in roll), f"  -> timed launch: {roll[-1][1]:.1f} us ({roll[-1][0]})")
+        short_i = min(range(len(roll)), key=lambda i: roll[i][1])  # the warm-up launch
+        timed = roll[short_i + 1] if short_i + 1 < len(roll) else roll[-1]
+        print("rollout dispatches in launch order, us:", ", ".join(f"{us:.1f}" for _, us in roll), f"  -> timed launch: {timed[1]:.1f} us ({timed[0]})")
     print("\n## PMC, separate passes; per kernel: mean per dispatch and the largest dispatch (rollout kernel: a 1000-step launch)")
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         for kern, cs in counters_by_kernel(os.path.join(d, sub), needle).items():
