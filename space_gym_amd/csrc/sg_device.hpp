@@ -924,8 +924,8 @@ SG_FN void steering(const SgDev &c, float a1, float om_cmd, float om_state, floa
 // discrete ones.  DiscreteSpaceshipEnv._translate_raw_action (spaceship_env.py:189-202) maps the index to
 // (engine, thruster) in {0,1} x {-1,0,1}; it is returned as the raw pair (2 engine - 1, thruster) that
 // translate_action() turns back into exactly that (engine, thruster).  Out-of-range indices act as 0 (the reference raises).
-SG_FN void load_action(const SgDev &c, const void *actions, int64_t idx, float &a0, float &a1) {
-    if (c.discrete_actions) {
+SG_FN void load_action(bool discrete, const void *actions, int64_t idx, float &a0, float &a1) {
+    if (discrete) {
         const int k = static_cast<const int32_t *>(actions)[idx];
         const bool engine = (k == 1) | (k == 4) | (k == 5);
         a0 = engine ? 1.0f : -1.0f;

@@ -29,7 +29,7 @@ static void goal_steps(const SgDev &c, int64_t m, const float *state, const floa
         int dn, ht;
         StepResult sr;
         float a0, a1;
-        load_action(c, action, i, a0, a1);
+        load_action(c.discrete_actions != 0, action, i, a0, a1);
         goal_env_step<N, ACCEL>(c, e, a0, a1, o, r, dn, ht, sr);
         float *s1 = state1 + 6 * i;
         s1[0] = e.x; s1[1] = e.y; s1[2] = e.th; s1[3] = e.vx; s1[4] = e.vy; s1[5] = e.om;
@@ -79,7 +79,7 @@ extern "C" int twin_step(const char *env_id, int64_t m, const float *state, cons
         int dn;
         StepResult sr;
         float a0, a1;
-        load_action(c, action, i, a0, a1);
+        load_action(c.discrete_actions != 0, action, i, a0, a1);
         if (g_steering_acceleration) kepler_env_step<true>(c, ob, e, a0, a1, o, r, dn, sr);
         else kepler_env_step<false>(c, ob, e, a0, a1, o, r, dn, sr);
         float *s1 = state1 + 6 * i;
