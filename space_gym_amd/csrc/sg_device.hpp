@@ -173,7 +173,7 @@ SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float
 //   NC circles with radii cR (Goal: the planets; Kepler: planet + border, both centred on the origin),
 //   the first NG of them gravitate; WALLS adds the world_max / world_min events (dynamic_model.py:196-208).
 //   The angular-velocity event (:210-212, limit 6) cannot fire: |omega| = |5 a1| <= 5 for actions in [-1, 1].
-enum : int { kRkContinue = 0, kRkFinished = 1, kRkEvent = 2 };
+enum : int { kRkContinue = 0, kRkFinished = 1, kRkEvent = 2, kRkEventDeferred = 3 };
 
 // ACCEL selects Steering.acceleration at compile time: the velocity-steering kernels (every registered id) carry none of it.
 template <int NC, int NG, bool WALLS, bool ACCEL = false>
@@ -190,27 +190,47 @@ struct Integrator {
     bool rejected;
     int n_rk, attempts;
 
+    // An accepted RK step over which at least one event function changed sign: everything solve_event() needs besides the
+    // env-step constants (set_constants).  The rollout kernel's pilot wave hands such cases to its finisher wave.
+    struct EventCase {
+        float h, t, X, Y, vx, vy, Xn, Yn;  // the step [t, t + h]: displacement and velocity at its start, displacement at its end
+        double Xd, Yd;                     // fp64 displacement at the start
+        float k0[4], k2[4], k3[4], k4[4], k5[4], k6[4];  // stages (vx, vy, ax, ay); stage 2 has zero dense-output weight
+        unsigned mask;                     // event functions with a sign change (bit NC + 2: angular velocity)
+        float s_w;                         // root of the angular-velocity event in [0, 1] (Steering.acceleration), else 2
+        int n_rk;
+        static constexpr int kWords = 8 + 4 + 24 + 3;
+    };
+
     // heading advance since t = 0: omega is constant (Steering.velocity) or linear in t (Steering.acceleration), so theta(t)
     // is known in closed form; RK45 integrates such polynomials exactly and its error estimate for them is 0.
     SG_MFN float phase(float tt) const { return ACCEL ? fmaf(om, tt, 0.5f * alpha * tt * tt) : om * tt; }
 
     // Steering.velocity: om_ = 5 a1 (the RHS overwrites omega, dynamic_model.py:138-141), alpha_ = 0.
     // Steering.acceleration: om_ = the state's omega, alpha_ = a1 * max_thruster_force / moi (dynamic_model.py:160-161,175).
-    SG_MFN void begin(float h_total, float half_world_, float gm_, float F_, float om_, float alpha_, float w_limit_,
-                      float x0_, float y0_, float th0, float vx0, float vy0, const float (&cax_)[NC],
-                      const float (&cay_)[NC], const float (&cR_)[NC], const double (&cRd_)[NC]) {
-        SG_STAMP(8);
+    // The constants of the env-step that the event solver needs (all of begin() except the RK state).
+    SG_MFN void set_constants(float h_total, float half_world_, float gm_, float F_, float om_, float alpha_, float w_limit_,
+                              float x0_, float y0_, const float (&cax_)[NC], const float (&cay_)[NC], const float (&cR_)[NC],
+                              const double (&cRd_)[NC]) {
         half_world = half_world_; gm = gm_; F = F_; om = om_; alpha = ACCEL ? alpha_ : 0.0f; w_limit = w_limit_;
         x0 = x0_; y0 = y0_;
 #pragma unroll
         for (int k = 0; k < NC; k++) { cax[k] = cax_[k]; cay[k] = cay_[k]; cR[k] = cR_[k]; cRd[k] = cRd_[k]; }
-        sincos_acc(th0, S0, C0);
         t_end = h_total;
+        // circle centres relative to the start position (fp32 working copy; the fp64 root polish uses cax/cay)
+#pragma unroll
+        for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x0; cqy[k] = cay[k] - y0; }
+        wxp = half_world - x0; wyp = half_world - y0; wxm = half_world + x0; wym = half_world + y0;
+    }
+
+    SG_MFN void begin(float h_total, float half_world_, float gm_, float F_, float om_, float alpha_, float w_limit_,
+                      float x0_, float y0_, float th0, float vx0, float vy0, const float (&cax_)[NC],
+                      const float (&cay_)[NC], const float (&cR_)[NC], const double (&cRd_)[NC]) {
+        SG_STAMP(8);
+        set_constants(h_total, half_world_, gm_, F_, om_, alpha_, w_limit_, x0_, y0_, cax_, cay_, cR_, cRd_);
+        sincos_acc(th0, S0, C0);
         t = 0.0f; X = 0.0f; Y = 0.0f; vx = vx0; vy = vy0;
         Xd = 0.0; Yd = 0.0;
-        // circle centres relative to the start position (fp32 working copy; the fp64 root polish uses cax/cay)
-    #pragma unroll
-        for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x0; cqy[k] = cay[k] - y0; }
 
         // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
         k0[0] = vx; k0[1] = vy;
@@ -245,14 +265,17 @@ struct Integrator {
         // event functions at (t0, y0), ivp.py:646
     #pragma unroll
         for (int k = 0; k < NC; k++) g[k] = fsqrt(fmaf(cqx[k], cqx[k], cqy[k] * cqy[k])) - cR[k];
-        wxp = half_world - x0; wyp = half_world - y0; wxm = half_world + x0; wym = half_world + y0;
         if (WALLS) { g[NC] = fminf(wxp, wyp); g[NC + 1] = fminf(wxm, wym); }
 
         rejected = false; n_rk = 0; attempts = 0;
     }
 
     // One RK attempt.  Returns kRkContinue, or fills `o` and returns kRkFinished / kRkEvent.
-    SG_MFN int attempt(StepResult &o) {
+    // `sink(ev)`: called for an accepted step with an event before it is solved; if it returns true the case has been taken
+    // over (o.done = 1, return value kRkEventDeferred), else it is solved here.
+    struct NoSink { SG_MFN bool operator()(const EventCase &) const { return false; } };
+    template <typename SINK = NoSink>
+    SG_MFN int attempt(StepResult &o, SINK &&sink = NoSink()) {
         // (t < t_end holds on entry: begin() starts at t = 0 and the exits below leave the loop once t_end is reached or the
         //  attempt budget is spent)
         attempts++;
@@ -364,126 +387,17 @@ struct Integrator {
         }
 
         if (mask) {
-            // dense output over [t, t_new]: y(s) = y_old + h s (K0 + s (Q1 + s (Q2 + s Q3))), s in [0, 1]
-            float q1[4], q2[4], q3[4];
+            EventCase ev;
+            ev.h = h; ev.t = t; ev.X = X; ev.Y = Y; ev.vx = vx; ev.vy = vy; ev.Xn = Xn; ev.Yn = Yn; ev.Xd = Xd; ev.Yd = Yd;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float d2_ = k2[i] - k0[i], d3_ = k3[i] - k0[i], d4_ = k4[i] - k0[i], d5_ = k5[i] - k0[i], d6_ = k6[i] - k0[i];
-                q1[i] = fmaf(P71, d6_, fmaf(P61, d5_, fmaf(P51, d4_, fmaf(P41, d3_, P31 * d2_))));
-                q2[i] = fmaf(P72, d6_, fmaf(P62, d5_, fmaf(P52, d4_, fmaf(P42, d3_, P32 * d2_))));
-                q3[i] = fmaf(P73, d6_, fmaf(P63, d5_, fmaf(P53, d4_, fmaf(P43, d3_, P33 * d2_))));
+            for (int i = 0; i < 4; i++) { ev.k0[i] = k0[i]; ev.k2[i] = k2[i]; ev.k3[i] = k3[i]; ev.k4[i] = k4[i]; ev.k5[i] = k5[i]; ev.k6[i] = k6[i]; }
+            ev.mask = mask; ev.s_w = s_w; ev.n_rk = n_rk;
+            if (sink(ev)) {
+                o.dXd = 0.0; o.dYd = 0.0; o.dX = 0.0f; o.dY = 0.0f; o.vx = 0.0f; o.vy = 0.0f; o.t = t; o.dth = 0.0f; o.om = om;
+                o.done = 1; o.event = -1; o.n_rk = n_rk;
+                return kRkEventDeferred;
             }
-            auto disp = [&](int i, float s) __attribute__((always_inline)) { return h * s * fmaf(s, fmaf(s, fmaf(s, q3[i], q2[i]), q1[i]), k0[i]); };
-            auto dispd = [&](int i, float s) __attribute__((always_inline)) {  // d disp / ds
-                return h * fmaf(s, fmaf(s, fmaf(4.0f * s, q3[i], 3.0f * q2[i]), 2.0f * q1[i]), k0[i]);
-            };
-            // Every event function is solved through SMOOTH components: a circle is one component; a wall event
-            // min(W/2 -+ x, W/2 -+ y) (dynamic_model.py:196-205) has a kink, so its x and y parts are solved separately
-            // and combined by the min semantics: leaving the world (g: + -> -) the first component to cross wins,
-            // entering it (g: - -> +, injected states only) the last one does.
-            float best = 2.0f;
-            int best_k = -1, best_comp = 0;
-            float bax = 0.0f, bay = 0.0f;  // absolute centre of the winning circle event
-            double bRd = 0.0;
-            unsigned m = mask & ((1u << (NC + 2)) - 1u);  // circle and wall events; the omega event is handled after them
-            while (m) {  // usually one active event; all are terminal -> the earliest root wins (ivp.py:115-126)
-                const int k = __builtin_ctz(m);
-                m &= m - 1;
-                // per-lane event description (selects, no dynamic register indexing)
-                float ecx = 0.0f, ecy = 0.0f, eR = 0.0f, eax = 0.0f, eay = 0.0f, g0 = 0.0f, g1 = 0.0f;
-                double eRd = 0.0;
-#pragma unroll
-                for (int j = 0; j < NC + (WALLS ? 2 : 0); j++)
-                    if (j == k) {
-                        g0 = g[j]; g1 = gn[j];
-                        if (j < NC) { ecx = cqx[j]; ecy = cqy[j]; eR = cR[j]; eax = cax[j]; eay = cay[j]; eRd = cRd[j]; }
-                    }
-                const bool circle = k < NC, leaving = g0 > 0.0f;
-                const float sgn = (k == NC) ? 1.0f : -1.0f;                      // world_max : world_min
-                const float wx = (k == NC) ? wxp : wxm, wy = (k == NC) ? wyp : wym;
-                // Two slots solved side by side (independent chains -> ILP for the lone wave):
-                //   slot A: the circle, or the x part of a wall event;   slot B: the y part of a wall event.
-                // Safeguarded Newton from the regula-falsi point; the parts are nearly linear in s over one RK step.
-                float gaA, gbA, gaB = 1.0f, gbB = 1.0f;
-                if (circle) { gaA = g0; gbA = g1; }
-                else { gaA = wx - sgn * X; gbA = wx - sgn * Xn; gaB = wy - sgn * Y; gbB = wy - sgn * Yn; }
-                const bool crossA = gaA * gbA <= 0.0f;  // sign change or a zero at either end (as for `mask`)
-                const bool crossB = !circle && gaB * gbB <= 0.0f;
-                float loA = 0.0f, hiA = 1.0f, loB = 0.0f, hiB = 1.0f;
-                float denA = gaA - gbA, denB = gaB - gbB;
-                float sA = (denA != 0.0f) ? fminf(fmaxf(gaA * rcp(denA), 0.0f), 1.0f) : 0.0f;
-                float sB = (denB != 0.0f) ? fminf(fmaxf(gaB * rcp(denB), 0.0f), 1.0f) : 0.0f;
-                for (int it = 0; it < kRootMaxIters; it++) {
-                    const float pA = sA, pB = sB;
-                    if (crossA) {  // slot A: circle or x part (branches are skipped wave-wide when no lane needs them)
-                        float gA, gpA;
-                        const float dxA = X + disp(0, sA), uxA = dispd(0, sA);
-                        if (circle) {
-                            const float dyA = Y + disp(1, sA), uyA = dispd(1, sA);
-                            const float exA = ecx - dxA, eyA = ecy - dyA;
-                            const float r2A = fmaf(exA, exA, eyA * eyA), irA = rsq(r2A);
-                            gA = r2A * irA - eR;
-                            gpA = -(exA * uxA + eyA * uyA) * irA;
-                        } else {
-                            gA = wx - sgn * dxA;
-                            gpA = -sgn * uxA;
-                        }
-                        if ((gA > 0.0f) == (gaA > 0.0f)) loA = sA; else hiA = sA;   // g(lo) keeps the sign of g(0)
-                        const float nA = sA - gA * rcp(gpA);
-                        sA = (nA > loA && nA < hiA) ? nA : ((gA == 0.0f) ? sA : 0.5f * (loA + hiA));
-                    }
-                    if (crossB) {  // slot B: y part of a wall event
-                        const float dyB = Y + disp(1, sB), uyB = dispd(1, sB);
-                        const float gB = wy - sgn * dyB, gpB = -sgn * uyB;
-                        if ((gB > 0.0f) == (gaB > 0.0f)) loB = sB; else hiB = sB;
-                        const float nB = sB - gB * rcp(gpB);
-                        sB = (nB > loB && nB < hiB) ? nB : ((gB == 0.0f) ? sB : 0.5f * (loB + hiB));
-                    }
-                    // well-conditioned roots settle in 2-3 passes; near-tangent grazes (slope ~ 0) keep going, bisecting
-                    const bool convA = !crossA || fabsf(sA - pA) <= 1e-6f, convB = !crossB || fabsf(sB - pB) <= 1e-6f;
-                    if (it >= kRootIters - 1 && convA && convB) break;
-                }
-                // the event function is the circle, or min(x part, y part): leaving the world the first part to cross
-                // wins, entering it (injected states only) the last one does
-                float root;
-                int root_comp = 0;
-                if (circle) root = sA;
-                else if (crossA && crossB) { const bool pickB = leaving ? (sB < sA) : (sB > sA); root = pickB ? sB : sA; root_comp = pickB; }
-                else if (crossB) { root = sB; root_comp = 1; }
-                else root = crossA ? sA : (leaving ? 2.0f : -1.0f);
-                if (root < best && root >= 0.0f) { best = root; best_k = k; best_comp = root_comp; bax = eax; bay = eay; bRd = eRd; }
-            }
-            // One Newton step on the winning component with g evaluated in fp64 from the unrounded inputs: the Goal
-            // reward multiplies the terminal position by up to 1000 (goal.py:147-152), so fp32 noise in g (~1e-7)
-            // would show.  The slope only needs a few digits.
-            if (best_k >= 0) {
-                const float s = best;
-                const float dx = X + disp(0, s), dy = Y + disp(1, s), ux = dispd(0, s), uy = dispd(1, s);
-                double gd;
-                float gp;
-                if (best_k < NC) {
-                    const double ex = ((double)bax - (double)x0) - (double)dx, ey = ((double)bay - (double)y0) - (double)dy;
-                    const double r2 = ex * ex + ey * ey, ir = rsqrt_f64(r2);
-                    gd = r2 * ir - bRd;
-                    gp = -((float)ex * ux + (float)ey * uy) * (float)ir;
-                } else {
-                    const double sg = (best_k == NC) ? 1.0 : -1.0, hw = (double)half_world;
-                    gd = best_comp ? hw - sg * ((double)y0 + (double)dy) : hw - sg * ((double)x0 + (double)dx);
-                    gp = (float)(-sg) * (best_comp ? uy : ux);
-                }
-                if (fabsf(gp) > 1e-12f) best = fminf(fmaxf(s - (float)gd * rcp(gp), 0.0f), 1.0f);
-            }
-            if (s_w < best) { best = s_w; best_k = NC + 2; }  // the omega event comes last in the reference's event order
-            const float s = best;
-            // leading term h s v in fp64, the O(h^2) remainder in fp32
-            const double hs = (double)h * (double)s;
-            o.dXd = Xd + (hs * (double)vx + (double)(h * s * s * fmaf(s, fmaf(s, q3[0], q2[0]), q1[0])));
-            o.dYd = Yd + (hs * (double)vy + (double)(h * s * s * fmaf(s, fmaf(s, q3[1], q2[1]), q1[1])));
-            o.dX = (float)o.dXd; o.dY = (float)o.dYd;
-            o.vx = vx + disp(2, s); o.vy = vy + disp(3, s);
-            o.t = fmaf(h, s, t);
-            o.dth = phase(o.t); o.om = ACCEL ? fmaf(alpha, o.t, om) : om;
-            o.done = 1; o.event = best_k; o.n_rk = n_rk;
+            solve_event(ev, o, g, gn);
             return kRkEvent;
         }
 #pragma unroll
@@ -494,6 +408,154 @@ struct Integrator {
         for (int i = 0; i < 4; i++) k0[i] = k6[i];
         if (!(t < t_end) || attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
         return kRkContinue;
+    }
+
+    // solve_ivp's event handling for an accepted step with sign changes (ivp.py:673-694): the earliest root over the
+    // step's 4th-order dense output (rk.py:178-192) becomes the end of the env-step.  Needs set_constants() only.
+    // g0 / g1: the event functions at the two ends of the step when the caller has them (attempt()); null: recomputed.
+    SG_MFN void solve_event(const EventCase &ev, StepResult &o, const float *g0 = nullptr, const float *g1 = nullptr) const {
+        const float h = ev.h, t = ev.t, X = ev.X, Y = ev.Y, vx = ev.vx, vy = ev.vy, Xn = ev.Xn, Yn = ev.Yn, s_w = ev.s_w;
+        const double Xd = ev.Xd, Yd = ev.Yd;
+        const unsigned mask = ev.mask;
+        const float(&k0)[4] = ev.k0, (&k2)[4] = ev.k2, (&k3)[4] = ev.k3, (&k4)[4] = ev.k4, (&k5)[4] = ev.k5, (&k6)[4] = ev.k6;
+        // event functions at both ends of the step, by the expressions attempt() / begin() use (X = Y = 0 at t = 0)
+        float g[NC + 2], gn[NC + 2];
+        if (g0) {
+#pragma unroll
+            for (int k = 0; k < NC + 2; k++) { g[k] = g0[k]; gn[k] = g1[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const float ax_ = cqx[k] - X, ay_ = cqy[k] - Y, bx_ = cqx[k] - Xn, by_ = cqy[k] - Yn;
+                g[k] = fsqrt(fmaf(ax_, ax_, ay_ * ay_)) - cR[k];
+                gn[k] = fsqrt(fmaf(bx_, bx_, by_ * by_)) - cR[k];
+            }
+            g[NC] = g[NC + 1] = gn[NC] = gn[NC + 1] = 1.0f;
+            if (WALLS) {
+                g[NC] = fminf(wxp - X, wyp - Y); g[NC + 1] = fminf(wxm + X, wym + Y);
+                gn[NC] = fminf(wxp - Xn, wyp - Yn); gn[NC + 1] = fminf(wxm + Xn, wym + Yn);
+            }
+        }
+        // dense output over [t, t_new]: y(s) = y_old + h s (K0 + s (Q1 + s (Q2 + s Q3))), s in [0, 1]
+        float q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float d2_ = k2[i] - k0[i], d3_ = k3[i] - k0[i], d4_ = k4[i] - k0[i], d5_ = k5[i] - k0[i], d6_ = k6[i] - k0[i];
+            q1[i] = fmaf(P71, d6_, fmaf(P61, d5_, fmaf(P51, d4_, fmaf(P41, d3_, P31 * d2_))));
+            q2[i] = fmaf(P72, d6_, fmaf(P62, d5_, fmaf(P52, d4_, fmaf(P42, d3_, P32 * d2_))));
+            q3[i] = fmaf(P73, d6_, fmaf(P63, d5_, fmaf(P53, d4_, fmaf(P43, d3_, P33 * d2_))));
+        }
+        auto disp = [&](int i, float s) __attribute__((always_inline)) { return h * s * fmaf(s, fmaf(s, fmaf(s, q3[i], q2[i]), q1[i]), k0[i]); };
+        auto dispd = [&](int i, float s) __attribute__((always_inline)) {  // d disp / ds
+            return h * fmaf(s, fmaf(s, fmaf(4.0f * s, q3[i], 3.0f * q2[i]), 2.0f * q1[i]), k0[i]);
+        };
+        // Every event function is solved through SMOOTH components: a circle is one component; a wall event
+        // min(W/2 -+ x, W/2 -+ y) (dynamic_model.py:196-205) has a kink, so its x and y parts are solved separately
+        // and combined by the min semantics: leaving the world (g: + -> -) the first component to cross wins,
+        // entering it (g: - -> +, injected states only) the last one does.
+        float best = 2.0f;
+        int best_k = -1, best_comp = 0;
+        float bax = 0.0f, bay = 0.0f;  // absolute centre of the winning circle event
+        double bRd = 0.0;
+        unsigned m = mask & ((1u << (NC + 2)) - 1u);  // circle and wall events; the omega event is handled after them
+        while (m) {  // usually one active event; all are terminal -> the earliest root wins (ivp.py:115-126)
+            const int k = __builtin_ctz(m);
+            m &= m - 1;
+            // per-lane event description (selects, no dynamic register indexing)
+            float ecx = 0.0f, ecy = 0.0f, eR = 0.0f, eax = 0.0f, eay = 0.0f, g0 = 0.0f, g1 = 0.0f;
+            double eRd = 0.0;
+#pragma unroll
+            for (int j = 0; j < NC + (WALLS ? 2 : 0); j++)
+                if (j == k) {
+                    g0 = g[j]; g1 = gn[j];
+                    if (j < NC) { ecx = cqx[j]; ecy = cqy[j]; eR = cR[j]; eax = cax[j]; eay = cay[j]; eRd = cRd[j]; }
+                }
+            const bool circle = k < NC, leaving = g0 > 0.0f;
+            const float sgn = (k == NC) ? 1.0f : -1.0f;                      // world_max : world_min
+            const float wx = (k == NC) ? wxp : wxm, wy = (k == NC) ? wyp : wym;
+            // Two slots solved side by side (independent chains -> ILP for the lone wave):
+            //   slot A: the circle, or the x part of a wall event;   slot B: the y part of a wall event.
+            // Safeguarded Newton from the regula-falsi point; the parts are nearly linear in s over one RK step.
+            float gaA, gbA, gaB = 1.0f, gbB = 1.0f;
+            if (circle) { gaA = g0; gbA = g1; }
+            else { gaA = wx - sgn * X; gbA = wx - sgn * Xn; gaB = wy - sgn * Y; gbB = wy - sgn * Yn; }
+            const bool crossA = gaA * gbA <= 0.0f;  // sign change or a zero at either end (as for `mask`)
+            const bool crossB = !circle && gaB * gbB <= 0.0f;
+            float loA = 0.0f, hiA = 1.0f, loB = 0.0f, hiB = 1.0f;
+            float denA = gaA - gbA, denB = gaB - gbB;
+            float sA = (denA != 0.0f) ? fminf(fmaxf(gaA * rcp(denA), 0.0f), 1.0f) : 0.0f;
+            float sB = (denB != 0.0f) ? fminf(fmaxf(gaB * rcp(denB), 0.0f), 1.0f) : 0.0f;
+            for (int it = 0; it < kRootMaxIters; it++) {
+                const float pA = sA, pB = sB;
+                if (crossA) {  // slot A: circle or x part (branches are skipped wave-wide when no lane needs them)
+                    float gA, gpA;
+                    const float dxA = X + disp(0, sA), uxA = dispd(0, sA);
+                    if (circle) {
+                        const float dyA = Y + disp(1, sA), uyA = dispd(1, sA);
+                        const float exA = ecx - dxA, eyA = ecy - dyA;
+                        const float r2A = fmaf(exA, exA, eyA * eyA), irA = rsq(r2A);
+                        gA = r2A * irA - eR;
+                        gpA = -(exA * uxA + eyA * uyA) * irA;
+                    } else {
+                        gA = wx - sgn * dxA;
+                        gpA = -sgn * uxA;
+                    }
+                    if ((gA > 0.0f) == (gaA > 0.0f)) loA = sA; else hiA = sA;   // g(lo) keeps the sign of g(0)
+                    const float nA = sA - gA * rcp(gpA);
+                    sA = (nA > loA && nA < hiA) ? nA : ((gA == 0.0f) ? sA : 0.5f * (loA + hiA));
+                }
+                if (crossB) {  // slot B: y part of a wall event
+                    const float dyB = Y + disp(1, sB), uyB = dispd(1, sB);
+                    const float gB = wy - sgn * dyB, gpB = -sgn * uyB;
+                    if ((gB > 0.0f) == (gaB > 0.0f)) loB = sB; else hiB = sB;
+                    const float nB = sB - gB * rcp(gpB);
+                    sB = (nB > loB && nB < hiB) ? nB : ((gB == 0.0f) ? sB : 0.5f * (loB + hiB));
+                }
+                // well-conditioned roots settle in 2-3 passes; near-tangent grazes (slope ~ 0) keep going, bisecting
+                const bool convA = !crossA || fabsf(sA - pA) <= 1e-6f, convB = !crossB || fabsf(sB - pB) <= 1e-6f;
+                if (it >= kRootIters - 1 && convA && convB) break;
+            }
+            // the event function is the circle, or min(x part, y part): leaving the world the first part to cross
+            // wins, entering it (injected states only) the last one does
+            float root;
+            int root_comp = 0;
+            if (circle) root = sA;
+            else if (crossA && crossB) { const bool pickB = leaving ? (sB < sA) : (sB > sA); root = pickB ? sB : sA; root_comp = pickB; }
+            else if (crossB) { root = sB; root_comp = 1; }
+            else root = crossA ? sA : (leaving ? 2.0f : -1.0f);
+            if (root < best && root >= 0.0f) { best = root; best_k = k; best_comp = root_comp; bax = eax; bay = eay; bRd = eRd; }
+        }
+        // One Newton step on the winning component with g evaluated in fp64 from the unrounded inputs: the Goal
+        // reward multiplies the terminal position by up to 1000 (goal.py:147-152), so fp32 noise in g (~1e-7)
+        // would show.  The slope only needs a few digits.
+        if (best_k >= 0) {
+            const float s = best;
+            const float dx = X + disp(0, s), dy = Y + disp(1, s), ux = dispd(0, s), uy = dispd(1, s);
+            double gd;
+            float gp;
+            if (best_k < NC) {
+                const double ex = ((double)bax - (double)x0) - (double)dx, ey = ((double)bay - (double)y0) - (double)dy;
+                const double r2 = ex * ex + ey * ey, ir = rsqrt_f64(r2);
+                gd = r2 * ir - bRd;
+                gp = -((float)ex * ux + (float)ey * uy) * (float)ir;
+            } else {
+                const double sg = (best_k == NC) ? 1.0 : -1.0, hw = (double)half_world;
+                gd = best_comp ? hw - sg * ((double)y0 + (double)dy) : hw - sg * ((double)x0 + (double)dx);
+                gp = (float)(-sg) * (best_comp ? uy : ux);
+            }
+            if (fabsf(gp) > 1e-12f) best = fminf(fmaxf(s - (float)gd * rcp(gp), 0.0f), 1.0f);
+        }
+        if (s_w < best) { best = s_w; best_k = NC + 2; }  // the omega event comes last in the reference's event order
+        const float s = best;
+        // leading term h s v in fp64, the O(h^2) remainder in fp32
+        const double hs = (double)h * (double)s;
+        o.dXd = Xd + (hs * (double)vx + (double)(h * s * s * fmaf(s, fmaf(s, q3[0], q2[0]), q1[0])));
+        o.dYd = Yd + (hs * (double)vy + (double)(h * s * s * fmaf(s, fmaf(s, q3[1], q2[1]), q1[1])));
+        o.dX = (float)o.dXd; o.dY = (float)o.dYd;
+        o.vx = vx + disp(2, s); o.vy = vy + disp(3, s);
+        o.t = fmaf(h, s, t);
+        o.dth = phase(o.t); o.om = ACCEL ? fmaf(alpha, o.t, om) : om;
+        o.done = 1; o.event = best_k; o.n_rk = ev.n_rk;
     }
 
     SG_MFN void finish(StepResult &o) const {
