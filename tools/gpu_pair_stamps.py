@@ -16,7 +16,8 @@ from space_gym_amd import _native  # noqa: E402
 SLOTS, WAVES = 16, 4096
 PILOT = {0: "top of step (action, loop)", 1: "begin: select_initial_step, g(t0)", 2: "RK attempts + event roots",
          3: "state update", 4: "wait for a ring slot", 5: "ring record + publish", 8: "TimeLimit + restart"}
-FIN = {0: "loop", 1: "wait for the pilot", 2: "everything else (reward, observation, stores, queue, resamples)"}
+FIN = {0: "loop", 1: "wait for the pilot", 3: "read record, event pass, release slot", 4: "reward + update + observe",
+       5: "owner stores", 6: "refill passes", 7: "restart: pop + cold stores + obs", 2: "goal resamples"}
 
 
 def main():
