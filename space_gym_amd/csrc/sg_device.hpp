@@ -1032,6 +1032,31 @@ SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a
     I.begin(c.h, c.half_world, c.gm, F, om0, alpha, c.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd);
 }
 
+// The same from a by-value copy of the few parameters it needs: a K-step loop keeps them in registers instead of re-reading
+// the parameter block every step.
+struct StepConsts {
+    float max_engine_force, h, half_world, gm, omega_limit, planet_r, max_thruster_force, inv_moi;
+    double planet_r_d;
+};
+SG_FN StepConsts step_consts(const SgDev &c) {
+    StepConsts k;
+    k.max_engine_force = c.max_engine_force; k.h = c.h; k.half_world = c.half_world; k.gm = c.gm; k.omega_limit = c.omega_limit;
+    k.planet_r = c.planet_r; k.max_thruster_force = c.max_thruster_force; k.inv_moi = c.inv_moi; k.planet_r_d = c.planet_r_d;
+    return k;
+}
+template <int N, bool ACCEL = false>
+SG_FN void goal_env_begin(const StepConsts &k, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true, ACCEL> &I) {
+    float engine, F, om, om0, alpha;
+    translate_action(a0, a1, k.max_engine_force, engine, F, om);
+    if (ACCEL) { om0 = e.om; alpha = (a1 * k.max_thruster_force) * k.inv_moi; }  // steering<ACCEL>
+    else { om0 = om; alpha = 0.0f; }
+    float cR[N];
+    double cRd[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { cR[j] = k.planet_r; cRd[j] = k.planet_r_d; }
+    I.begin(k.h, k.half_world, k.gm, F, om0, alpha, k.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd);
+}
+
 template <int N>
 SG_FN void goal_env_finish(const SgDev &c, GoalEnv<N> &e, const StepResult &r, float (&obs)[7 + 2 * N + 2],
                            float &reward, int &done, int &hit) {
