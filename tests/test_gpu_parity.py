@@ -290,6 +290,11 @@ def test_fused_rollout_ragged_batches(n):
         _fused_vs_step_by_step(env_id, max_episode_steps=40, n=n)
 
 
+def test_fused_rollout_more_workgroups_than_cus():
+    """a grid with more wave-pair workgroups than CUs (they are resident one per CU at a time and take turns)"""
+    _fused_vs_step_by_step("GoalContinuous3P-v0", max_episode_steps=30, K=96, split=40, n=70000)
+
+
 def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100, auto_reset=True, n=8192):
     import torch
     gen = torch.Generator(device="cuda").manual_seed(3)
