@@ -3,17 +3,21 @@
 (BASELINE.json `metric`, configs[2]); one process per GPU, weak scaling, no data-path collective.
 
     python bench.py --gpus 1 --steps 1000 --warmup 100
+    python bench.py --gpus N ...            (spawns N ranks itself through torch.distributed.run, relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the hot path over the whole per-GPU batch (integrate + events + observation + reward + goal
 resample + TimeLimit + auto-reset for every env).  Inputs (U(-1,1) action blocks) are resident in HBM before the timed
 region; outputs go to a [steps, B, ...] rollout buffer in HBM.  The timed region is ONE sg_rollout_device call for the K
 steps: for the Goal ids that is one launch of the K-step rollout kernel (env state in registers across steps); the same K
-steps as K launches of the per-step kernel are timed too and reported beside it.  Prints ONE JSON line on rank 0.
+steps as K launches of the per-step kernel (what a policy-in-the-loop user gets) are timed too and reported beside it with
+their own roofline block.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,14 +34,15 @@ def algorithmic_bytes_per_env_step(env_id):
     return 113 + 16 * s["n_planets"] if s["family"] == "goal" else 109
 
 
-def measured_traffic(env_id, batch, steps_per_launch):
+def measured_traffic(env_id, batch, kernel_name, steps_per_launch):
     """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 for 16 B/lane streams, WRITE_SIZE), taken
-    offline with tools/gpu_profile.sh and committed under profiles/; null when no measurement matches this workload."""
+    offline with tools/gpu_profile.sh and committed under profiles/; null unless a measurement of THIS kernel on this
+    workload exists (the per-step part scales with the steps per launch)."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if t.get("env_id") == env_id and t.get("batch") == batch:
-            return t["hbm_bytes_per_launch"] * steps_per_launch / t["steps_per_launch"]
-    except (OSError, ValueError, KeyError):
+        for t in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["measurements"]:
+            if t["env_id"] == env_id and t["batch"] == batch and t["kernel"] == kernel_name:
+                return t["hbm_bytes_per_launch"] * steps_per_launch / t["steps_per_launch"]
+    except (OSError, ValueError, KeyError, TypeError):
         pass
     return None
 
@@ -62,26 +67,46 @@ def usable_cores():
 
 def cpu_baseline(env_id, batch, budget_s=12.0):
     """The fp64 CPU oracle (oracle/, a restatement of the reference's NumPy/scipy path pinned to its golden vectors)
-    on the same workload, all host cores of this box, bounded sample.  Reported beside the GPU number, never as it."""
+    on the same workload on this box's host cores, bounded sample: all usable cores (`value`) and one core
+    (`single_core`).  Reported beside the GPU number, never as it."""
     import numpy as np
     from oracle import Oracle
-    cores = usable_cores()
-    o = Oracle(env_id, threads=cores)
-    n = min(batch, 65536)
-    envs, _ = o.vec_reset(n, seed=0)
     rng = np.random.default_rng(1)
-    acts = [rng.uniform(-1, 1, size=(n, 2)).astype(np.float32) for _ in range(8)]
-    for i in range(3):  # warm-up
-        o.vec_step(envs, acts[i], seed=0)
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < budget_s:
-        o.vec_step(envs, acts[steps % 8], seed=0)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} vector steps of {n} envs ({env_id}, random U(-1,1) actions, auto-reset on), "
-                      f"{dt:.1f} s, OpenMP over {cores} threads, fp64 RK45 oracle"}
+
+    def sample(threads, n, budget):
+        o = Oracle(env_id, threads=threads)
+        envs, _ = o.vec_reset(n, seed=0)
+        acts = [rng.uniform(-1, 1, size=(n, 2)).astype(np.float32) for _ in range(8)]
+        for i in range(2):  # warm-up
+            o.vec_step(envs, acts[i], seed=0)
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < budget:
+            o.vec_step(envs, acts[steps % 8], seed=0)
+            steps += 1
+        dt = time.perf_counter() - t0
+        return n * steps / dt, f"{steps} vector steps of {n} envs ({env_id}, random U(-1,1) actions, auto-reset on), {dt:.1f} s"
+
+    cores = usable_cores()
+    v_all, s_all = sample(cores, min(batch, 65536), budget_s * 0.65)
+    v_one, s_one = sample(1, min(batch, 4096), budget_s * 0.35)
+    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": s_all + f", OpenMP over {cores} threads, fp64 RK45 oracle",
+            "single_core": {"value": v_one, "cores": 1, "sample": s_one + ", one thread"}}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` as a plain command: start N fresh ranks through torch.distributed.run BEFORE anything in
+    this process touches the GPU, relay their output (rank 0 prints the JSON line) and leave with their exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -99,25 +124,28 @@ def main():
                     "the others are reported as ms_per_step_repeats / ms_per_step_median")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline sample")
     ap.add_argument("--preroll", type=int, default=12000,
-                    help="untimed steps run before the warm-up steps, as part of the set-up: ~50 ms of the same kernel, so that "
-                         "the GPU has left its idle clocks before anything is measured (a 100-step warm-up alone is 0.4 ms; "
-                         "measured: 4.38 us/step right after idle, 4.09 after 13 ms, 3.55 after 50 ms of work, same kernel)")
+                    help="untimed steps run before the warm-up steps, as part of the set-up: ~40 ms of the same kernel, so that "
+                         "the GPU has left its idle clocks and the envs have their stationary mix of episode ages before "
+                         "anything is measured (a 100-step warm-up alone is 0.3 ms)")
     ap.add_argument("--chunk", type=int, default=2000, help="max steps per sg_rollout_device call / rollout buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time a per-step RCCL gather of (obs,reward,done) to rank 0")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the NumPy host-buffer path sample (sg_step, PCIe-inclusive)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     import torch.distributed as dist
     import space_gym_amd as sg
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     # Rehearsal aid: SG_BENCH_REHEARSE=1 runs all ranks on GPU 0 with the gloo backend, to exercise the multi-rank logic on a
@@ -134,7 +162,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
-    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B)
+    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B, copy=False)
     D = env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
@@ -143,11 +171,13 @@ def main():
     ring = max(1, min(args.action_ring if args.action_ring > 0 else chunk, chunk))
     if args.action_source == "engine":  # sg_random_actions_device: Philox keyed by (seed, global env index, step)
         actions = env.random_actions_torch(ring, seed=1)
+    elif env.discrete:
+        actions = torch.randint(0, 6, (ring, B), generator=gen, device=dev, dtype=torch.int32)
     else:
         actions = torch.rand((ring, B, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
     nbuf = chunk
     # rollout buffers in HBM (3.9 GB of observations at K=1000, B=65536, D=15)
-    act_seq = actions.repeat((nbuf + ring - 1) // ring, 1, 1)[:nbuf].contiguous()
+    act_seq = actions.repeat((nbuf + ring - 1) // ring, *([1] * (actions.dim() - 1)))[:nbuf].contiguous()
     obs = torch.empty((nbuf, B, D), device=dev, dtype=torch.float32)
     rew = torch.empty((nbuf, B), device=dev, dtype=torch.float32)
     done = torch.empty((nbuf, B), device=dev, dtype=torch.uint8)
@@ -162,12 +192,17 @@ def main():
                 dist.barrier(device_ids=[dev_index])
             torch.cuda.synchronize(dev)
 
+    prepared = {}
+
     def run_steps(n):
-        """n steps as ceil(n / chunk) sg_rollout_device calls into the (reused) rollout buffers; returns #finished episodes"""
+        """n steps as ceil(n / chunk) sg_rollout_device calls into the (reused) rollout buffers; the buffers of a call are
+        validated once (prepare_rollout), the call itself is one C function"""
         left = n
         while left > 0:
             k = min(left, chunk)
-            env.rollout_torch(act_seq[:k], obs[:k], rew[:k], done[:k], trunc[:k])
+            if k not in prepared:
+                prepared[k] = env.prepare_rollout(act_seq[:k], obs[:k], rew[:k], done[:k], trunc[:k])
+            prepared[k]()
             left -= k
 
     env.reset_torch()
@@ -176,17 +211,20 @@ def main():
     run_steps(W)
     sync_all()
 
-    # ---- timed region: exactly K steps, no instrumentation; one HIP event pair on the launch stream brackets it
+    # ---- timed region: exactly K steps, no instrumentation; one HIP event pair on the launch stream brackets it.  The
+    # events exist before the region starts (torch creates them on their first record()).
     timing = not args.no_kernel_timing
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); ev1.record()
     sync_all()
     t0 = time.perf_counter()
-    ev0.record()  # torch's current stream == the stream rollout_torch launches on
+    ev0.record()  # torch's current stream == the stream the rollout is launched on
     run_steps(K)
     ev1.record()
     sync_all()
     dt = time.perf_counter() - t0
-    stream_ms_per_launch = ev0.elapsed_time(ev1) / K  # kernel + inter-kernel gap
+    stream_ms_per_step = ev0.elapsed_time(ev1) / K  # kernel + inter-kernel gap
+    env.check_status()  # a rollout whose wave hand-off timed out is not a measurement
     # ---- the same K-step region repeated (SURVEY 8d asks for >= 5 repeats and their median); `value` stays the first one
     repeats = [dt]
     for _ in range(max(0, args.repeats - 1)):
@@ -196,28 +234,41 @@ def main():
         sync_all()
         repeats.append(time.perf_counter() - tr)
 
-    # ---- the same K steps again with start/stop events on every dispatch (hipExtLaunchKernelGGL): the kernel's own
-    # duration, as rocprofv3 --kernel-trace reports it.  Costs ~35% throughput, hence not done in the region above.
     # ---- A/B: the same K steps as K launches of the per-step kernel (what a policy-in-the-loop user gets)
     env.set_unfused_rollout(True)
+    step_kernel_name = env.rollout_kernel(1)
+    run_steps(min(K, 50))
     sync_all()
     t_u = time.perf_counter()
     run_steps(K)
     sync_all()
     dt_unfused = time.perf_counter() - t_u
+    u_launches, u_ms, u_min, u_max = 0, 0.0, 0.0, 0.0
+    if timing:  # the per-step kernel's own duration (dispatch start/stop events)
+        env.set_profiling(True)
+        sync_all()
+        run_steps(K)
+        sync_all()
+        u_launches, u_ms, u_min, u_max = env.get_profile()
+        env.set_profiling(False)
     env.set_unfused_rollout(False)
 
+    # ---- the same K steps again with start/stop events on every dispatch (hipExtLaunchKernelGGL): the kernel's own
+    # duration, as rocprofv3 --kernel-trace reports it
     launches, kern_ms, kmin, kmax, dt_events = 0, 0.0, 0.0, 0.0, None
     kernel_name = env.rollout_kernel(min(K, chunk))
     if timing:
+        run_steps(K)
         env.set_profiling(True)
         sync_all()
         t1 = time.perf_counter()
-        run_steps(K)
+        for _ in range(max(1, args.repeats)):
+            run_steps(K)
         sync_all()
-        dt_events = time.perf_counter() - t1
+        dt_events = (time.perf_counter() - t1) / max(1, args.repeats)
         launches, kern_ms, kmin, kmax = env.get_profile()
         env.set_profiling(False)
+    env.check_status()
 
     gather_ms = None
     if args.gather and world > 1:
@@ -233,6 +284,17 @@ def main():
         sync_all()
         gather_ms = (time.perf_counter() - t2) * 1e3 / K
 
+    host_us = None
+    if world == 1 and not args.no_host_path:  # NumPy in / out through sg_step: H2D + kernel + D2H per step (PCIe-inclusive)
+        a_host = act_seq[0].cpu().numpy()
+        for _ in range(3):
+            env.step(a_host)
+        th = time.perf_counter()
+        n_host = 20
+        for _ in range(n_host):
+            env.step(a_host)
+        host_us = (time.perf_counter() - th) * 1e6 / n_host
+
     red_dev = torch.device("cpu") if rehearse else dev
     stats = torch.tensor([dt, dt_unfused, dt_events or 0.0], device=red_dev, dtype=torch.float64)
     k_last = K - (K - 1) // chunk * chunk  # steps in the last chunk, whose outputs are still in the buffers
@@ -245,7 +307,7 @@ def main():
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(args.env)
         out = {
-            "metric": "env-steps/sec at batch=65536, GoalContinuous3P-v0, 1/2/4/8 MI355X",
+            "metric": f"env-steps/sec at batch={B}, {args.env}, 1/2/4/8 MI355X",
             "value": world * B * K / dt_max, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -259,16 +321,17 @@ def main():
         }
         if timing and launches:
             avg_us = kern_ms * 1e3 / launches
-            steps_per_launch = K / launches
+            steps_per_launch = K * max(1, args.repeats) / launches
             achieved = steps_per_launch * B * bytes_per / (avg_us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.env, B, steps_per_launch),
+                               "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": measured_traffic(args.env, B, kernel_name, steps_per_launch),
                                "kernel": kernel_name,
                                "env_steps_per_launch": steps_per_launch * B, "steps_per_launch": steps_per_launch,
                                "kernel_avg_us": avg_us, "kernel_min_us": kmin * 1e3, "kernel_max_us": kmax * 1e3,
                                "launches": launches, "timing": "hipExtLaunchKernelGGL start/stop events on each of the "
-                               f"{launches} dispatches of a second, identical {K}-step pass",
-                               "stream_event_us_per_step_in_timed_region": stream_ms_per_launch * 1e3,
+                               f"{launches} dispatches of {max(1, args.repeats)} further, identical {K}-step passes",
+                               "stream_event_us_per_step_in_timed_region": stream_ms_per_step * 1e3,
                                "algorithmic_bytes_per_env_step": bytes_per,
                                "algorithmic_bytes_per_launch": steps_per_launch * B * bytes_per}
             out["value_with_dispatch_events"] = world * B * K / dt_events
@@ -276,6 +339,17 @@ def main():
         out["ms_per_step_median"] = sorted(out["ms_per_step_repeats"])[len(repeats) // 2]
         out["value_one_launch_per_step"] = world * B * K / dt_unfused
         out["ms_per_step_one_launch_per_step"] = dt_unfused * 1e3 / K
+        if timing and u_launches:
+            u_avg = u_ms * 1e3 / u_launches
+            u_ach = B * bytes_per / (u_avg * 1e-6) / 1e9
+            out["roofline_one_launch_per_step"] = {
+                "bound": "hbm", "achieved": u_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u_ach / HBM_PEAK_GBS,
+                "traffic": measured_traffic(args.env, B, step_kernel_name, 1), "kernel": step_kernel_name,
+                "kernel_avg_us": u_avg, "kernel_min_us": u_min * 1e3, "kernel_max_us": u_max * 1e3, "launches": u_launches}
+        if host_us is not None:
+            out["host_numpy_path"] = {"us_per_step": host_us, "value": B / (host_us * 1e-6), "unit": "env-steps/s",
+                                      "what": "sg_step with NumPy arrays in page-locked memory: H2D of the actions, the step "
+                                              "kernel, D2H of obs / reward / done / truncated per step (PCIe-inclusive; never `value`)"}
         if gather_ms is not None:
             out["ms_per_step_with_rccl_gather"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:

@@ -13,6 +13,9 @@
  *     device memory on the handle's GPU, owned by the caller;
  *   - no allocation, no host synchronisation and no host<->device copy inside the *_device calls:
  *     they only enqueue kernels on the given stream (hipGraph-capturable);
+ *   - the host-buffer calls (sg_reset, sg_step, sg_get_state, sg_set_state, sg_vector_field, sg_save_state, sg_load_state,
+ *     sg_seed, sg_set_auto_reset) run on the handle's own stream, wait for whatever the *_device calls have enqueued on
+ *     the caller's streams before, and return when they are complete -- no manual synchronisation between the two kinds;
  *   - a handle is not thread-safe; independent handles are.
  *   - observations/rewards are float32 (the reference returns float64; parity tolerance in DESIGN.md).
  */
@@ -94,6 +97,29 @@ int sg_rollout_device(sg_env *env, int32_t n_steps, const void *actions_dev, flo
                       uint8_t *done_dev, uint8_t *truncated_dev, void *hip_stream);
 int sg_set_unfused_rollout(sg_env *env, int32_t on);
 
+/* The same rollout, also returning what a finished env's LAST observation was: in obs[t] a finished env already shows the
+ * first observation of its next episode (VectorEnv convention), so the observation SpaceshipEnv.step returned with
+ * done=True (spaceship_env.py:75-78) -- needed to bootstrap from truncated episodes -- would otherwise be lost.  One record
+ * per finished env-step is appended to the list, in no particular order (device memory, owned by the caller):
+ *   count     uint32 [1]            records appended by this call (set to 0 first); it keeps counting past `capacity`, the
+ *                                   excess records are dropped -- size the list for n_steps * num_envs * (finish rate ~2 %)
+ *   step_env  int32  [capacity, 2]  (step within this call, env index) of each record
+ *   obs       float32 [capacity, obs_dim]
+ * With auto_reset off nothing is appended (obs[t] is the terminal observation itself). */
+typedef struct sg_terminal_list {
+    uint32_t *count;
+    int32_t *step_env;
+    float *obs;
+    uint32_t capacity;
+} sg_terminal_list;
+int sg_rollout_device_terminal(sg_env *env, int32_t n_steps, const void *actions_dev, float *obs_dev, float *reward_dev,
+                               uint8_t *done_dev, uint8_t *truncated_dev, const sg_terminal_list *list, void *hip_stream);
+
+/* The wave-pair rollout kernels bound every wait between their waves; a wait that runs out (never, on working hardware)
+ * invalidates that rollout and is recorded on the handle: every later call on the handle then fails with SG_ERR_HIP until
+ * sg_check_status -- which waits for the work enqueued so far, reports the condition and clears it -- has been called. */
+int sg_check_status(sg_env *env);
+
 /* On-device action source for sg_rollout_device: the uniformly random policy (what the reference's README loop and the
  * benchmark use: env.action_space.sample(), gym spaces Box / Discrete).  Fills actions_dev [n_steps, num_envs, 2] float32
  * with i.i.d. U(-1, 1) values (discrete ids: int32 [n_steps, num_envs] uniform in 0..5).  Entry (t, i) is a function of
@@ -109,6 +135,15 @@ int sg_random_actions_device(sg_env *env, int32_t n_steps, uint64_t seed, uint64
  *   elapsed int32   [num_envs]      steps taken in the current episode */
 int sg_get_state(sg_env *env, float *ship, float *planets, float *goal, int32_t *elapsed);
 int sg_set_state(sg_env *env, const float *ship, const float *planets, const float *goal, const int32_t *elapsed);
+
+/* Complete snapshot of a handle (checkpoint / restore), as an opaque blob of sg_state_bytes(env) bytes of host memory: every
+ * per-env column -- ship, planets, goal / orbit, step and episode counters, and the tiling state HexagonalTiling keeps
+ * between goal hits (hexagonal_tiling.py:99-128: free-tile list, ship / goal tile, column shifts) -- plus the RNG key.
+ * Loading it into a handle of the same env id and batch size makes the following steps bit-identical to those that
+ * followed the save. */
+size_t sg_state_bytes(const sg_env *env);
+int sg_save_state(sg_env *env, void *blob_host, size_t bytes);
+int sg_load_state(sg_env *env, const void *blob_host, size_t bytes);
 
 /* SpaceshipEnv.vector_field(raw_action, state_vec=None) (spaceship_env.py:96-100): the RHS of the ODE,
  * out float32 [num_envs, 6] = (vx, vy, omega', ax, ay, angular acceleration) at each env's current planets and either its

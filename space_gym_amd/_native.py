@@ -15,6 +15,10 @@ class SgConfig(C.Structure):
                 ("steering", C.c_int32)]
 
 
+class SgTerminalList(C.Structure):
+    _fields_ = [("count", C.c_void_p), ("step_env", C.c_void_p), ("obs", C.c_void_p), ("capacity", C.c_uint32)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -37,6 +41,11 @@ SYMBOLS = {
     "sg_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sg_rollout_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sg_set_unfused_rollout": (C.c_int, [_vp, C.c_int32]),
+    "sg_rollout_device_terminal": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.POINTER(SgTerminalList), _vp]),
+    "sg_check_status": (C.c_int, [_vp]),
+    "sg_state_bytes": (C.c_size_t, [_vp]),
+    "sg_save_state": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "sg_load_state": (C.c_int, [_vp, _vp, C.c_size_t]),
     "sg_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sg_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sg_vector_field": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -66,7 +75,12 @@ def load():
         pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        try:
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        except AttributeError:
+            if not os.environ.get("SPACEGYM_LIB"):
+                raise
+            continue  # an older diagnostic build of the same library (A/B measurements): newer entry points are absent
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib

@@ -4,9 +4,10 @@ Envs never interact (gym_space/dynamic_model.py:145-165 sums only an env's own p
 contiguous blocks -- rank k owns global envs [k*B/W, (k+1)*B/W) -- and `step_local` involves no communication at all.
 The RNG is keyed by the GLOBAL env index (sg_config.env_index_base), so results do not depend on the number of ranks.
 
-Only the single-process VectorEnv view needs a collective: `step(actions)` scatters rank 0's [B, 2] actions and gathers one
-packed buffer per rank -- obs | reward | done | truncated -- back to rank 0 (a rooted gather: on the fully connected xGMI
-mesh every peer uses its own link to the root once; no ring, no all-reduce).
+Only the single-process VectorEnv view needs a collective: `step(actions)` scatters rank 0's actions ([B, 2] float32, or [B]
+int32 indices for the discrete ids) and gathers one packed buffer per rank -- obs | [terminal obs] | reward | done |
+truncated -- back to rank 0 (a rooted gather: on the fully connected xGMI mesh every peer uses its own link to the root
+once; no ring, no all-reduce).
 """
 import numpy as np
 import torch
@@ -21,34 +22,47 @@ def shard_bounds(num_envs, world_size, rank):
 
 
 class PackedResult:
-    """obs f32 [n, D] | reward f32 [n] | done u8 [n] | truncated u8 [n] in ONE flat uint8 buffer (one message per rank)."""
+    """obs f32 [n, D] | (terminal obs f32 [n, D]) | reward f32 [n] | done u8 [n] | truncated u8 [n] in ONE flat uint8
+    buffer (one message per rank)."""
 
-    def __init__(self, n, obs_dim, device):
-        self.n, self.d = n, obs_dim
-        self.o_obs, self.o_rew = 0, 4 * n * obs_dim
-        self.o_done = self.o_rew + 4 * n
-        self.o_trunc = self.o_done + n
-        self.nbytes = self.o_trunc + n
+    def __init__(self, n, obs_dim, device, with_terminal=False):
+        self.n, self.d, self.with_terminal = n, obs_dim, bool(with_terminal)
+        self.nbytes = self.size(n, obs_dim, with_terminal)
         self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
 
     @staticmethod
-    def views(buf, n, d):
-        o_rew = 4 * n * d
-        o_done = o_rew + 4 * n
-        return (buf[:o_rew].view(torch.float32).view(n, d), buf[o_rew:o_done].view(torch.float32),
-                buf[o_done:o_done + n], buf[o_done + n:o_done + 2 * n])
+    def size(n, d, with_terminal=False):
+        return 4 * n * d * (2 if with_terminal else 1) + 4 * n + 2 * n
 
-    def fill(self, obs, reward, done, trunc):
-        o, r, dn, tr = self.views(self.buf, self.n, self.d)
-        o.copy_(obs); r.copy_(reward); dn.copy_(done.to(torch.uint8)); tr.copy_(trunc.to(torch.uint8))
+    @staticmethod
+    def views(buf, n, d, with_terminal=False):
+        """(obs, reward, done, truncated[, terminal obs]) views into a packed buffer"""
+        o_end = 4 * n * d
+        t_end = o_end + (4 * n * d if with_terminal else 0)
+        r_end = t_end + 4 * n
+        out = (buf[:o_end].view(torch.float32).view(n, d), buf[t_end:r_end].view(torch.float32),
+               buf[r_end:r_end + n], buf[r_end + n:r_end + 2 * n])
+        if with_terminal:
+            out += (buf[o_end:t_end].view(torch.float32).view(n, d),)
+        return out
+
+    def fill(self, obs, reward, done, trunc, tobs=None):
+        v = self.views(self.buf, self.n, self.d, self.with_terminal)
+        v[0].copy_(obs); v[1].copy_(reward); v[2].copy_(done.to(torch.uint8)); v[3].copy_(trunc.to(torch.uint8))
+        if self.with_terminal:
+            v[4].copy_(tobs)
         return self.buf
 
 
 class ShardedVectorEnv:
     """`local_env` is the per-rank engine: by default a SpaceGymVectorEnv on this rank's GPU.  Tests inject a stand-in with
-    the same three methods (reset_tensors, step_tensors, close) to exercise the sharding and the collectives on CPU/gloo."""
+    the same interface -- reset_tensors(), step_tensors(actions) -> (obs, reward, done, truncated[, terminal obs]), close(),
+    attributes obs_dim and discrete -- to exercise the sharding and the collectives on CPU/gloo.
 
-    def __init__(self, env_id, num_envs, seed=0, group=None, device=None, local_env=None, **kwargs):
+    terminal_observation=True adds the last observation of every finished episode to what step() returns (rows of envs
+    that did not finish are NaN): the `info["terminal_observation"]` of a gym VectorEnv."""
+
+    def __init__(self, env_id, num_envs, seed=0, group=None, device=None, local_env=None, terminal_observation=False, **kwargs):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (one process per GPU)")
         self.group = group
@@ -57,22 +71,27 @@ class ShardedVectorEnv:
         self.lo, self.hi = shard_bounds(num_envs, self.world, self.rank)
         self.n_local = self.hi - self.lo
         self.counts = [shard_bounds(num_envs, self.world, r) for r in range(self.world)]
+        self.with_terminal = bool(terminal_observation)
         if local_env is None:
             from .vector_env import SpaceGymVectorEnv
             dev_index = torch.cuda.current_device() if device is None else int(device)
             eng = SpaceGymVectorEnv(env_id, self.n_local, device=dev_index, seed=seed, env_index_base=self.lo, **kwargs)
-            local_env = _TorchEngineAdapter(eng)
+            local_env = _TorchEngineAdapter(eng, self.with_terminal)
             self.device = torch.device("cuda", dev_index)
         else:
             self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.local = local_env
         self.obs_dim = local_env.obs_dim
-        self._packed = PackedResult(self.n_local, self.obs_dim, self.device)
+        self.discrete = bool(getattr(local_env, "discrete", False))
+        self._packed = PackedResult(self.n_local, self.obs_dim, self.device, self.with_terminal)
         self._gather_bufs = None
         if self.rank == 0:
-            self._gather_bufs = [torch.empty(PackedResult(hi - lo, self.obs_dim, "cpu").nbytes, dtype=torch.uint8,
+            self._gather_bufs = [torch.empty(PackedResult.size(hi - lo, self.obs_dim, self.with_terminal), dtype=torch.uint8,
                                              device=self.device) for lo, hi in self.counts]
-        self._act_local = torch.empty((self.n_local, 2), dtype=torch.float32, device=self.device)
+        # the env's action spec: one int32 index per env for the discrete ids (spaceship_env.py:183-202), else float32 [2]
+        self._act_dtype = torch.int32 if self.discrete else torch.float32
+        self._act_shape = (self.n_local,) if self.discrete else (self.n_local, 2)
+        self._act_local = torch.empty(self._act_shape, dtype=self._act_dtype, device=self.device)
 
     # ---- no communication: each rank drives its own shard (learner on the same GPU)
     def reset_local(self):
@@ -82,8 +101,8 @@ class ShardedVectorEnv:
         return self.local.step_tensors(actions_local)
 
     # ---- single-process view on rank 0
-    def _gather(self, obs, reward, done, trunc):
-        buf = self._packed.fill(obs, reward, done, trunc)
+    def _gather(self, obs, reward, done, trunc, tobs=None):
+        buf = self._packed.fill(obs, reward, done, trunc, tobs)
         if self.world == 1:
             parts = [buf]
         elif _equal_sizes(self.counts):
@@ -100,21 +119,23 @@ class ShardedVectorEnv:
             parts = self._gather_bufs
         if self.rank != 0:
             return None
-        outs = [PackedResult.views(p, hi - lo, self.obs_dim) for p, (lo, hi) in zip(parts, self.counts)]
-        return tuple(torch.cat([o[k] for o in outs]) for k in range(4))
+        outs = [PackedResult.views(p, hi - lo, self.obs_dim, self.with_terminal) for p, (lo, hi) in zip(parts, self.counts)]
+        return tuple(torch.cat([o[k] for o in outs]) for k in range(5 if self.with_terminal else 4))
 
     def reset(self):
         obs = self.local.reset_tensors()
         z = torch.zeros(self.n_local, device=self.device)
-        out = self._gather(obs, z, z.to(torch.uint8), z.to(torch.uint8))
+        out = self._gather(obs, z, z.to(torch.uint8), z.to(torch.uint8), torch.full_like(obs, float("nan")) if self.with_terminal else None)
         return out[0] if out is not None else None
 
     def step(self, actions=None):
-        """Rank 0 passes float32 [num_envs, 2]; other ranks pass None.  Rank 0 gets (obs, reward, done, truncated) for all
-        envs, other ranks None."""
+        """Rank 0 passes the actions of all envs (float32 [num_envs, 2]; discrete ids: int32 [num_envs]); other ranks pass
+        None.  Rank 0 gets (obs, reward, done, truncated[, terminal obs]) for all envs, other ranks None."""
         if self.world > 1:
             if self.rank == 0:
-                a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
+                a = torch.as_tensor(actions, dtype=self._act_dtype, device=self.device)
+                if tuple(a.shape) != ((self.num_envs,) if self.discrete else (self.num_envs, 2)):
+                    raise ValueError(f"actions of shape {tuple(a.shape)} for {self.num_envs} envs (discrete={self.discrete})")
                 chunks = [a[lo:hi].contiguous() for lo, hi in self.counts]
             if _equal_sizes(self.counts):
                 dist.scatter(self._act_local, chunks if self.rank == 0 else None, src=0, group=self.group)
@@ -125,7 +146,7 @@ class ShardedVectorEnv:
             else:
                 dist.recv(self._act_local, src=0, group=self.group)
         else:
-            self._act_local.copy_(torch.as_tensor(actions, dtype=torch.float32, device=self.device))
+            self._act_local.copy_(torch.as_tensor(actions, dtype=self._act_dtype, device=self.device))
         return self._gather(*self.local.step_tensors(self._act_local))
 
     def close(self):
@@ -137,14 +158,22 @@ def _equal_sizes(counts):
 
 
 class _TorchEngineAdapter:
-    def __init__(self, eng):
-        self.eng, self.obs_dim = eng, eng.obs_dim
+    """SpaceGymVectorEnv's device-tensor path behind the local-engine interface of ShardedVectorEnv"""
+
+    def __init__(self, eng, with_terminal=False):
+        self.eng, self.obs_dim, self.discrete = eng, eng.obs_dim, eng.discrete
+        self._tobs = None
+        if with_terminal:
+            self._tobs = torch.empty((eng.num_envs, eng.obs_dim), dtype=torch.float32, device=torch.device("cuda", eng.device))
 
     def reset_tensors(self):
         return self.eng.reset_torch()
 
     def step_tensors(self, actions):
-        return self.eng.step_torch(actions.contiguous())
+        if self._tobs is None:
+            return self.eng.step_torch(actions.contiguous())
+        self._tobs.fill_(float("nan"))  # the kernel writes the rows of finished envs only
+        return self.eng.step_torch(actions.contiguous(), terminal_obs=self._tobs) + (self._tobs,)
 
     def close(self):
         self.eng.close()

@@ -207,6 +207,8 @@ class SpaceGymVectorEnv:
     def reset_torch(self, out=None):
         torch, bufs = self._torch()
         obs = bufs["obs"] if out is None else out
+        if out is not None:
+            self._check_tensor("out", out, torch.float32, (self.num_envs, self.obs_dim))
         self._ck(self._lib.sg_reset_device(self._h, C.c_void_p(obs.data_ptr()), self._stream()), "sg_reset_device")
         return obs
 
@@ -219,8 +221,15 @@ class SpaceGymVectorEnv:
         o = bufs if out is None else out
         if not isinstance(actions, torch.Tensor) and hasattr(actions, "__dlpack__"):
             actions = torch.from_dlpack(actions)
-        want = (torch.int32, (self.num_envs,)) if self.discrete else (torch.float32, (self.num_envs, 2))
-        assert actions.is_cuda and actions.is_contiguous() and (actions.dtype, tuple(actions.shape)) == want, want
+        B, D = self.num_envs, self.obs_dim
+        self._check_tensor("actions", actions, torch.int32 if self.discrete else torch.float32, (B,) if self.discrete else (B, 2))
+        if out is not None:
+            self._check_tensor("out['obs']", o["obs"], torch.float32, (B, D))
+            self._check_tensor("out['reward']", o["reward"], torch.float32, (B,))
+            self._check_tensor("out['done']", o["done"], torch.uint8, (B,))
+            self._check_tensor("out['trunc']", o["trunc"], torch.uint8, (B,))
+        if terminal_obs is not None:
+            self._check_tensor("terminal_obs", terminal_obs, torch.float32, (B, D))
         rc = self._lib.sg_step_device(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(o["obs"].data_ptr()),
                                       C.c_void_p(o["reward"].data_ptr()), C.c_void_p(o["done"].data_ptr()),
                                       C.c_void_p(o["trunc"].data_ptr()),
@@ -228,15 +237,116 @@ class SpaceGymVectorEnv:
         self._ck(rc, "sg_step_device")
         return o["obs"], o["reward"], o["done"], o["trunc"]
 
-    def rollout_torch(self, actions, obs, reward, done, trunc):
-        """actions [K, B, 2] (discrete ids: int32 [K, B]) -> obs [K, B, D], reward/done/trunc [K, B]: K steps, one launch."""
-        K = actions.shape[0]
-        rc = self._lib.sg_rollout_device(self._h, int(K), C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
-                                         C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),
-                                         C.c_void_p(trunc.data_ptr()), self._stream())
-        self._ck(rc, "sg_rollout_device")
+    def _check_tensor(self, name, t, dtype, shape):
+        """a raw pointer goes to the kernel: refuse anything whose memory is not what the kernel will write / read"""
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device.index == self.device):
+            raise ValueError(f"{name}: expected a CUDA tensor on device {self.device}")
+        if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise ValueError(f"{name}: expected contiguous {dtype} of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)}"
+                             f"{'' if t.is_contiguous() else ' (not contiguous)'}")
+
+    def rollout_torch(self, actions, obs, reward, done, trunc, terminal=None):
+        """actions [K, B, 2] (discrete ids: int32 [K, B]) -> obs [K, B, D], reward/done/trunc [K, B]: K steps, one launch.
+        terminal: optional dict(count=uint32/int32 [1], step_env=int32 [cap, 2], obs=float32 [cap, D]) of device tensors
+        that receives one record per finished env-step: its (step, env) and the LAST observation of the episode that ended
+        there (sg_rollout_device_terminal); `terminal_records` turns it into sorted host arrays."""
+        import torch
+        K, B, D = int(actions.shape[0]), self.num_envs, self.obs_dim
+        self._check_tensor("actions", actions, torch.int32 if self.discrete else torch.float32, (K, B) if self.discrete else (K, B, 2))
+        self._check_tensor("obs", obs, torch.float32, (K, B, D))
+        self._check_tensor("reward", reward, torch.float32, (K, B))
+        self._check_tensor("done", done, torch.uint8, (K, B))
+        self._check_tensor("trunc", trunc, torch.uint8, (K, B))
+        args = (self._h, K, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()), C.c_void_p(reward.data_ptr()),
+                C.c_void_p(done.data_ptr()), C.c_void_p(trunc.data_ptr()))
+        if terminal is None:
+            self._ck(self._lib.sg_rollout_device(*args, self._stream()), "sg_rollout_device")
+        else:
+            cap = int(terminal["step_env"].shape[0])
+            if terminal["count"].dtype not in (torch.int32, torch.uint32) or terminal["count"].numel() != 1:
+                raise ValueError("terminal['count']: expected one 32-bit integer")
+            self._check_tensor("terminal['step_env']", terminal["step_env"], torch.int32, (cap, 2))
+            self._check_tensor("terminal['obs']", terminal["obs"], torch.float32, (cap, D))
+            tl = _native.SgTerminalList(terminal["count"].data_ptr(), terminal["step_env"].data_ptr(), terminal["obs"].data_ptr(), cap)
+            self._ck(self._lib.sg_rollout_device_terminal(*args, C.byref(tl), self._stream()), "sg_rollout_device_terminal")
         return obs, reward, done, trunc
 
+    def prepare_rollout(self, actions, obs, reward, done, trunc):
+        """Validates the buffers once and returns a zero-argument callable that enqueues the rollout on torch's current
+        stream: for loops that re-use the same buffers (the per-call checks of rollout_torch cost more host time than a
+        short rollout takes on the GPU)."""
+        import torch
+        K, B, D = int(actions.shape[0]), self.num_envs, self.obs_dim
+        self._check_tensor("actions", actions, torch.int32 if self.discrete else torch.float32, (K, B) if self.discrete else (K, B, 2))
+        self._check_tensor("obs", obs, torch.float32, (K, B, D))
+        self._check_tensor("reward", reward, torch.float32, (K, B))
+        self._check_tensor("done", done, torch.uint8, (K, B))
+        self._check_tensor("trunc", trunc, torch.uint8, (K, B))
+        keep = (actions, obs, reward, done, trunc)  # the callable keeps the tensors alive
+        args = (self._h, K) + tuple(C.c_void_p(t.data_ptr()) for t in keep)
+        fn, ck, dev = self._lib.sg_rollout_device, self._ck, self.device
+        cur = torch.cuda.current_stream
+
+        def call():
+            ck(fn(*args, C.c_void_p(cur(dev).cuda_stream)), "sg_rollout_device")
+        call.keep = keep
+        return call
+
+    def terminal_list_torch(self, capacity):
+        """device buffers for rollout_torch(..., terminal=...)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        return dict(count=torch.zeros(1, dtype=torch.int32, device=dev), step_env=torch.empty((capacity, 2), dtype=torch.int32, device=dev),
+                    obs=torch.empty((capacity, self.obs_dim), dtype=torch.float32, device=dev))
+
+    @staticmethod
+    def terminal_records(terminal):
+        """(step int32 [n], env int32 [n], obs float32 [n, D]) sorted by (step, env); raises if the list overflowed"""
+        n = int(terminal["count"].item())
+        cap = int(terminal["step_env"].shape[0])
+        if n > cap:
+            raise OverflowError(f"terminal list overflow: {n} records, capacity {cap}")
+        se = terminal["step_env"][:n].cpu().numpy()
+        ob = terminal["obs"][:n].cpu().numpy()
+        order = np.lexsort((se[:, 1], se[:, 0]))
+        return se[order, 0], se[order, 1], ob[order]
+
+    def check_status(self):
+        """waits for the enqueued work; raises if a rollout kernel's bounded wave hand-off wait ran out (sg_check_status)"""
+        self._ck(self._lib.sg_check_status(self._h), "sg_check_status")
+
+    # ------------------------------------------------------------------ complete snapshot
+    def save_state(self):
+        """opaque uint8 blob with every per-env column (incl. the tiling state and episode counters) and the RNG key"""
+        n = int(self._lib.sg_state_bytes(self._h))
+        blob = np.empty(n, np.uint8)
+        self._ck(self._lib.sg_save_state(self._h, self._ptr(blob), n), "sg_save_state")
+        return blob
+
+    def load_state(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self._ck(self._lib.sg_load_state(self._h, self._ptr(blob), blob.size), "sg_load_state")
+
+    SNAPSHOT_HEADER_BYTES = 48
+
+    def snapshot_columns(self, blob):
+        """introspection of a save_state() blob: the engine's per-env columns as NumPy views --
+        q0 (x, y, theta, vx), q1 (vy, omega, goal_x, goal_y | orbit angle, eccentricity), ctr (elapsed, episode),
+        aux (goal draws, ship_tile | goal_tile << 8 | case_b << 16 | flip << 17, free-tile multiset lo, hi),
+        Goal: pl0 / pl1 (two planets each), cshift (tiling column shifts); KeplerRandomOrbits: orbd (cos, sin of the angle)"""
+        B, off, out = self.num_envs, self.SNAPSHOT_HEADER_BYTES, {}
+        cols = [("q0", np.float32, 4), ("q1", np.float32, 4), ("ctr", np.uint32, 2), ("aux", np.uint32, 4)]
+        if self.spec["family"] == "goal":
+            cols += [("pl0", np.float32, 4)] + ([("pl1", np.float32, 4)] if self.n_planets > 2 else []) + [("cshift", np.float32, 4)]
+        elif self.env_id == "KeplerRandomOrbits-v0":
+            cols += [("orbd", np.float64, 2)]
+        for name, dt, w in cols:
+            nb = B * w * np.dtype(dt).itemsize
+            out[name] = np.frombuffer(blob, dtype=dt, count=B * w, offset=off).reshape(B, w)
+            off += nb
+        assert off == blob.size, (off, blob.size)
+        return out
 
     def random_actions_torch(self, n_steps, seed=0, first_step=0, out=None):
         """the uniformly random policy generated on the device: [n_steps, B, 2] float32 in (-1, 1) (discrete ids: int32

@@ -561,7 +561,8 @@ def test_vector_field_matches_reference():
 
 
 def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (tiny sizes here)"""
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (tiny sizes here); the metric
+    names the workload that ran"""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "64", "--warmup", "8", "--preroll", "16",
@@ -571,11 +572,17 @@ def test_bench_line_contract():
     assert len(lines) == 1
     b = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "roofline_one_launch_per_step", "host_numpy_path"):
         assert k in b, k
+    assert b["metric"] == "env-steps/sec at batch=4096, GoalContinuous3P-v0, 1/2/4/8 MI355X"
     assert b["steps"] == 64 and b["warmup"] == 8 and b["n_gpus"] == 1 and b["unit"] == "env-steps/s" and b["higher_is_better"]
     assert abs(b["value"] - 4096 * 64 / (b["ms_per_step"] * 64e-3)) / b["value"] < 1e-6
     r = b["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "kernel" in r
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"].startswith("goal_pair_rollout_kernel<3") and r["steps_per_launch"] == 64
+    assert r["traffic"] is None  # no PMC profile of this workload is committed: nothing is borrowed from another one
+    u = b["roofline_one_launch_per_step"]
+    assert u["kernel"].startswith("goal_pair_step_kernel<3") and u["launches"] == 64
     c = b["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s"
+    assert c["single_core"]["cores"] == 1 and 0 < c["single_core"]["value"] <= c["value"] * 1.5

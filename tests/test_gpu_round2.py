@@ -1,0 +1,341 @@
+"""GPU tests added in round 2: the rollout path checked DIRECTLY against the oracle, adversarial events and reset statistics
+on the card, terminal observations of rollouts, complete snapshots, stream ordering, the large-batch plan branch."""
+import numpy as np
+import pytest
+
+from cases import adversarial_event_cases, check_reset_statistics
+from conftest import FAMILIES, load_golden
+from oracle import Oracle
+from test_gpu_parity import TOL_OBS, TOL_REWARD_REL, TOL_STATE, check_against, make
+
+pytestmark = pytest.mark.gpu
+
+
+def _rollout_buffers(env, K):
+    import torch
+    n, D = env.num_envs, env.obs_dim
+    return (torch.empty((K, n, D), device="cuda"), torch.empty((K, n), device="cuda"),
+            torch.empty((K, n), dtype=torch.uint8, device="cuda"), torch.empty((K, n), dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.parametrize("env_id,n,K", [("GoalContinuous3P-v0", 65536, 64), ("GoalContinuous4P-v0", 16384, 48)])
+def test_pair_rollout_matches_oracle_directly(env_id, n, K):
+    """sg_rollout_device (ONE launch of the wave-pair kernel: pilot / finisher hand-off, batched event roots, episode queue)
+    against the oracle, step by step, at the headline batch -- not through the step kernel.  The oracle needs the exact
+    pre-step state of every step; a second handle with the same seed is stepped one launch at a time with sg_get_state in
+    between (its outputs must be bit-identical to the rollout's, which is asserted, so its states are the rollout's)."""
+    import torch
+    a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 2 - 1
+    env = make(env_id, n, seed=13)
+    assert env.rollout_kernel(K).startswith("goal_pair_rollout_kernel")
+    env.reset_torch()
+    pre = 40  # let episodes age: restarts, goal hits and a filled episode queue are all in play during the checked steps
+    obs, rew, done, trunc = _rollout_buffers(env, K)
+    env.rollout_torch(a[:pre], obs[:pre], rew[:pre], done[:pre], trunc[:pre])
+    term = env.terminal_list_torch(capacity=n * K // 8)
+    env.rollout_torch(a, obs, rew, done, trunc, terminal=term)
+    env.check_status()
+    obs, rew, done, trunc = (x.cpu().numpy() for x in (obs, rew, done, trunc))
+    t_step, t_env, t_obs = env.terminal_records(term)
+    last_obs = obs.copy()
+    last_obs[t_step, t_env] = t_obs
+    assert len(t_step) == int(done.sum())  # one record per finished env-step
+    env.close()
+
+    ref_env = make(env_id, n, seed=13)
+    o = Oracle(env_id, threads=16)
+    ref_env.reset()
+    a_h = a.cpu().numpy()
+    for t in range(pre):
+        ref_env.step(a_h[t])
+    worst = 0
+    for t in range(K):
+        st = ref_env.get_state()
+        ob, rw, dn, info = ref_env.step(a_h[t])
+        # the two handles are the same env bit for bit
+        assert np.array_equal(ob, obs[t]) and np.array_equal(rw, rew[t]) and np.array_equal(dn, done[t].astype(bool))
+        ref = o.step(st["ship"].astype(np.float64), a_h[t], st["planets"].astype(np.float64), st["goal"].astype(np.float64))
+        ref_done = ref["done"].astype(bool) | trunc[t].astype(bool)
+        same = done[t].astype(bool) == ref_done
+        worst = max(worst, int((~same).sum()))
+        assert (~same).sum() <= max(2, n // 20000)  # inputs within fp32 rounding of an event boundary
+        assert np.abs(last_obs[t][same] - ref["obs"][same]).max() <= TOL_OBS
+        rel = np.abs(rew[t][same] - ref["reward"][same]) / np.maximum(1.0, np.abs(ref["reward"][same]))
+        assert rel.max() <= TOL_REWARD_REL, (t, rel.max())
+        # the 7 leading observation slots are the state (x, y, cos, sin, vx, vy, omega)
+        s1 = ref["state1"][same]
+        assert np.abs(last_obs[t][same][:, [0, 1, 4, 5, 6]] - s1[:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
+    assert done.sum() > n // 2  # restarts, and with them the event hand-over, were exercised throughout
+    ref_env.close()
+
+
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "KeplerEllipseHard-v0"])
+def test_event_roots_on_grazing_and_corner_cases_gpu(env_id):
+    """the adversarial terminal steps of tests/test_host_twin.py on the card (v_rsq / v_rcp / v_log / v_exp instead of libm):
+    injected through sg_set_state, one sg_step, against the oracle"""
+    o = Oracle(env_id, threads=16)
+    outs = []
+    for seed in (3, 4, 5):
+        s0, a, P, g = adversarial_event_cases(o, n=60000, seed=seed)
+        m = len(s0)
+        env = make(env_id, m, seed=1, auto_reset=False)
+        env.reset()
+        env.set_state(ship=s0, planets=P, goal=g, elapsed=np.zeros(m, np.int32))
+        obs, rew, done, info = env.step(a)
+        s1 = env.get_state()["ship"]
+        env.close()
+        ref = o.step(s0.astype(np.float64), a, None if P is None else P.astype(np.float64), None if g is None else g.astype(np.float64))
+        assert (ref["done"] == 1).mean() > 0.4
+        assert np.array_equal(done, ref["done"].astype(bool))  # no event decision differs
+        check_against(obs, rew, done, s1, ref["state1"], ref["obs"], ref["reward"], ref["done"])
+        outs.append(m)
+    assert sum(outs) > 150000
+
+
+@pytest.mark.parametrize("fam", ["goal2p", "goal3p", "goal4p"])
+def test_reset_distribution_matches_reference_gpu(fam):
+    """GPU-generated resets and goal-resample chains against the statistics of 1e5 resets of the reference
+    (tests/golden/reset_*.npz): the reset kernel, then `hits` goal hits forced by parking the ship on its goal (engine off,
+    no velocity) so that every env resamples in every step (goal.py:154-157 -> hexagonal_tiling.py:95-128)."""
+    ref = load_golden("reset_" + fam)
+    n, hits = int(ref["n_resets"]), int(ref["n_hits"])
+    env = make(FAMILIES[fam], n, seed=777, auto_reset=False)
+    env.reset()
+    st0 = env.get_state()
+    cols0 = env.snapshot_columns(env.save_state())
+    goals, ship_tile, goal_tile, free = [st0["goal"].copy()], [], [], []
+
+    def tiles(c):
+        ship_tile.append((c["aux"][:, 1] & 0xff).astype(np.int64)); goal_tile.append(((c["aux"][:, 1] >> 8) & 0xff).astype(np.int64))
+        free.append(c["aux"][:, 2].astype(np.uint64) | (c["aux"][:, 3].astype(np.uint64) << np.uint64(32)))
+    tiles(cols0)
+    off = np.zeros((n, 2), np.float32); off[:, 0] = -1.0  # engine off, no turn
+    park = np.zeros((n, 6), np.float32)
+    alive = np.ones(n, bool)
+    for k in range(hits):
+        park[:, :2] = goals[-1]
+        env.set_state(ship=park)
+        obs, rew, done, info = env.step(off)
+        alive &= ~done
+        c = env.snapshot_columns(env.save_state())
+        assert (c["aux"][alive, 0] == k + 1).all()  # every parked env hit its goal and drew a new one
+        goals.append(env.get_state()["goal"].copy())
+        tiles(c)
+    env.close()
+    assert alive.mean() > 0.999  # (a ship parked on a goal next to a planet may drift into it within the step)
+    flags = np.array([((cols0["aux"][:, 1] >> 16) & 1).sum(), ((cols0["aux"][:, 1] >> 17) & 1).sum()])
+    check_reset_statistics(ref, fam, st0["ship"][alive], st0["planets"][alive], np.stack(goals, 1)[alive], np.stack(ship_tile, 1)[alive],
+                           np.stack(goal_tile, 1)[alive], np.stack(free, 1)[alive], cols0["cshift"][alive], flags * alive.mean())
+
+
+@pytest.mark.parametrize("env_id,kernel", [("GoalContinuous3P-v0", "pair"), ("GoalContinuous2P-v0", "single"),
+                                           ("KeplerCircleOrbit-v0", "pair"), ("GoalDiscrete4-v0", "pair")])
+def test_rollout_terminal_observations(env_id, kernel, monkeypatch):
+    """sg_rollout_device_terminal: one record per finished env-step with the LAST observation of the episode that ended
+    (what the reference's step returns with done=True, spaceship_env.py:75-78), bit-identical to the step kernel's
+    terminal_obs rows; the ordinary outputs are those of sg_rollout_device."""
+    import torch
+    monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", kernel)
+    n, K = 8192, 160
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    a = (torch.randint(0, 6, (K, n), device="cuda", generator=gen, dtype=torch.int32) if "Discrete" in env_id
+         else torch.rand((K, n, 2), device="cuda", generator=gen) * 2 - 1)
+    env = make(env_id, n, seed=6, max_episode_steps=45)
+    env.reset_torch()
+    obs, rew, done, trunc = _rollout_buffers(env, K)
+    term = env.terminal_list_torch(capacity=n * K // 4)
+    env.rollout_torch(a[:60], obs[:60], rew[:60], done[:60], trunc[:60], terminal=term)
+    first = env.terminal_records(term)
+    env.rollout_torch(a[60:], obs[60:], rew[60:], done[60:], trunc[60:], terminal=term)  # the count restarts with every call
+    second = env.terminal_records(term)
+    env.check_status()
+    env.close()
+    t_step = np.concatenate([first[0], second[0] + 60]); t_env = np.concatenate([first[1], second[1]])
+    t_obs = np.concatenate([first[2], second[2]])
+    # step by step with the step kernel's terminal_obs
+    ref = make(env_id, n, seed=6, max_episode_steps=45)
+    ref.reset_torch()
+    tob = torch.full((n, ref.obs_dim), float("nan"), device="cuda")
+    want_rows, want_obs = [], []
+    for t in range(K):
+        ob, rw, dn, tr = ref.step_torch(a[t].contiguous(), terminal_obs=tob)
+        torch.cuda.synchronize()
+        assert torch.equal(ob, obs[t]) and torch.equal(rw, rew[t]) and torch.equal(dn, done[t]) and torch.equal(tr, trunc[t])
+        idx = torch.nonzero(dn).flatten().cpu().numpy()
+        want_rows += [(t, int(i)) for i in idx]
+        want_obs.append(tob[idx].cpu().numpy())
+    ref.close()
+    want_obs = np.concatenate(want_obs)
+    assert len(want_rows) > n and len(want_rows) == len(t_step)
+    assert np.array_equal(np.array(want_rows), np.stack([t_step, t_env], 1))
+    assert np.array_equal(want_obs, t_obs)
+    assert (trunc.sum() > 0) and (done.sum() > trunc.sum())  # both kinds of endings were covered
+
+
+def test_terminal_list_overflow_is_reported():
+    import torch
+    n, K = 4096, 64
+    env = make("GoalContinuous3P-v0", n, seed=6, max_episode_steps=10)
+    env.reset_torch()
+    a = torch.rand((K, n, 2), device="cuda") * 2 - 1
+    obs, rew, done, trunc = _rollout_buffers(env, K)
+    term = env.terminal_list_torch(capacity=100)
+    env.rollout_torch(a, obs, rew, done, trunc, terminal=term)
+    torch.cuda.synchronize()
+    assert int(term["count"].item()) == int(done.sum().item()) > 100
+    with pytest.raises(OverflowError):
+        env.terminal_records(term)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous4P-v0", "KeplerRandomOrbits-v0"])
+def test_snapshot_restore_is_bit_identical(env_id):
+    """save_state -> K steps -> load_state -> the same K steps again: every output identical, with goal hits (the tiling's
+    free-tile multiset, ship / goal tile and goal-draw counter, hexagonal_tiling.py:99-128), restarts and truncations in
+    between; and a snapshot loaded into a NEW handle continues the same way."""
+    import torch
+    n, K = 8192, 120
+    a = torch.rand((2 * K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(8)) * 2 - 1
+    env = make(env_id, n, seed=31, max_episode_steps=50)
+    env.reset_torch()
+    obs, rew, done, trunc = _rollout_buffers(env, K)
+    env.rollout_torch(a[:K], obs, rew, done, trunc)  # some history first
+    blob = env.save_state()
+    cols = env.snapshot_columns(blob)
+    if env_id.startswith("Goal"):
+        assert (cols["aux"][:, 0] > 0).sum() > n // 50  # envs that have hit a goal in their current episode
+    runs = []
+    for rep in range(2):
+        env.rollout_torch(a[K:], obs, rew, done, trunc)
+        torch.cuda.synchronize()
+        runs.append([x.cpu().numpy().copy() for x in (obs, rew, done, trunc)] + [env.save_state()])
+        env.load_state(blob)
+    other = make(env_id, n, seed=999, max_episode_steps=50)  # another seed: the snapshot carries the RNG key
+    other.load_state(blob)
+    rec = []
+    for t in range(K):  # and through the one-launch-per-step kernel
+        o_, r_, d_, info = other.step(a[K + t].cpu().numpy())
+        rec.append((o_, r_, d_))
+    for x, y in zip(runs[0], runs[1]):
+        assert np.array_equal(x, y)
+    for t in range(K):
+        assert np.array_equal(rec[t][0], runs[0][0][t]) and np.array_equal(rec[t][1], runs[0][1][t])
+        assert np.array_equal(rec[t][2], runs[0][2][t].astype(bool))
+    assert np.array_equal(other.save_state()[48:], runs[0][4][48:])
+    assert runs[0][2].sum() > n
+    with pytest.raises(Exception):
+        make("GoalContinuous3P-v0", n).load_state(blob)
+    env.close(); other.close()
+
+
+def test_host_calls_are_ordered_after_device_calls():
+    """host-buffer calls (the handle's own stream) wait for the *_device work enqueued on the caller's stream: no manual
+    synchronisation between step_torch / rollout_torch and get_state / reset / set_state"""
+    import torch
+    n, K = 65536, 200
+    a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 2 - 1
+    synced, unsynced = make("GoalContinuous3P-v0", n, seed=4), make("GoalContinuous3P-v0", n, seed=4)
+    bufs = _rollout_buffers(synced, K)
+    for env, sync in ((synced, True), (unsynced, False)):
+        env.reset_torch()
+        env.rollout_torch(a, *bufs)          # ~0.6 ms of work in flight
+        if sync:
+            torch.cuda.synchronize()
+        st = env.get_state()
+        env.step_torch(a[0].contiguous())
+        if sync:
+            torch.cuda.synchronize()
+        st2 = env.get_state()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):       # a second caller stream
+            env.rollout_torch(a[:50], *(b[:50] for b in bufs))
+        if sync:
+            torch.cuda.synchronize()
+        blob = env.save_state()
+        env.results = (st, st2, blob)
+    for x, y in zip(synced.results[:2], unsynced.results[:2]):
+        for k in ("ship", "planets", "goal", "elapsed"):
+            assert np.array_equal(x[k], y[k]), k
+    assert np.array_equal(synced.results[2], unsynced.results[2])
+    unsynced.check_status()
+    synced.close(); unsynced.close()
+
+
+def test_large_batch_plan_branch_4p():
+    """config 5's per-GPU plan at its real size on one card: GoalContinuous4P-v0 with 524 288 envs (2 048 workgroups, more
+    than four per CU: the one-wave rollout kernel with the shallow episode queue).  The fused rollout equals the step
+    kernel bit for bit and the invariants hold."""
+    import torch
+    n, K = 524288, 24
+    env = make("GoalContinuous4P-v0", n, seed=2, max_episode_steps=12)
+    assert env.rollout_kernel(K) == "goal_rollout_kernel<4, false, 2>"
+    a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)) * 2 - 1
+    outs = []
+    for mode in (0, 1):
+        env.set_unfused_rollout(mode)
+        env.seed(2); env.reset_torch()
+        bufs = _rollout_buffers(env, K)
+        env.rollout_torch(a, *bufs)
+        torch.cuda.synchronize()
+        outs.append([b.cpu() for b in bufs] + [env.get_state()])
+        del bufs
+    for x, y in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(x, y)
+    for k in ("ship", "planets", "goal", "elapsed"):
+        assert np.array_equal(outs[0][4][k], outs[1][4][k])
+    obs, rew, done, trunc = outs[0][:4]
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert int(done.sum()) > n and int(trunc.sum()) > n // 2
+    assert (obs[..., :2].abs() <= 1.5).all() and ((obs[..., 2] ** 2 + obs[..., 3] ** 2 - 1).abs() < 1e-5).all()
+    env.close()
+
+
+def test_bench_two_ranks_as_a_plain_command():
+    """`python bench.py --gpus 2` spawns its ranks itself (rehearsal mode: both on this card, gloo) and prints one line"""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SG_BENCH_REHEARSE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--batch", "8192", "--preroll", "200"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["global_batch"] == 16384 and "cpu_baseline" not in b
+    assert abs(b["value"] - 2 * 8192 * 20 / (b["ms_per_step"] * 20e-3)) / b["value"] < 1e-6
+
+
+@pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "GoalDiscrete3-v0"])
+def test_sharded_env_on_the_gpu_adapter(env_id):
+    """ShardedVectorEnv over the real engine (_TorchEngineAdapter, device tensors), one rank: what the gloo tests cannot
+    reach.  Equals a plain SpaceGymVectorEnv step for step, terminal observations included, for both action specs."""
+    import os, socket
+    import torch
+    import torch.distributed as dist
+    from space_gym_amd.sharded import ShardedVectorEnv
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        n = 4096
+        sh = ShardedVectorEnv(env_id, n, seed=12, device=0, terminal_observation=True, max_episode_steps=30)
+        ref = make(env_id, n, seed=12, max_episode_steps=30)
+        assert sh.discrete == ref.discrete and (sh.lo, sh.hi) == (0, n)
+        assert np.array_equal(sh.reset().cpu().numpy(), ref.reset())
+        rng = np.random.default_rng(4)
+        n_done = 0
+        for t in range(80):
+            a = rng.integers(0, 6, n).astype(np.int32) if ref.discrete else rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+            obs, rew, done, trunc, tobs = (x.cpu().numpy() for x in sh.step(a))
+            o2, r2, d2, info = ref.step(a)
+            assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(done.astype(bool), d2)
+            assert np.array_equal(trunc.astype(bool), info["TimeLimit.truncated"])
+            assert np.array_equal(tobs[d2], info["terminal_observation"][d2]) and np.isnan(tobs[~d2]).all()
+            n_done += int(d2.sum())
+        assert n_done > n
+        sh.close(); ref.close()
+    finally:
+        dist.destroy_process_group()

@@ -59,3 +59,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "spacegym_oracle" not in src, f
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` as a plain command (no torchrun around it): the parent starts two fresh ranks through
+    torch.distributed.run before touching any GPU, relays their output and leaves with their exit code.  Without a GPU
+    each rank stops at the engine's "no CPU path" check -- which is what this CPU test sees, twice."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SG_BENCH_REHEARSE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--batch", "512", "--preroll", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300,
+                         env=env, cwd=ROOT)
+    if has_gpu():
+        assert out.returncode == 0, out.stderr[-2000:]
+        import json
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1 and json.loads(line[0])["n_gpus"] == 2
+    else:
+        assert out.returncode != 0
+        assert (out.stdout + out.stderr).count("bench.py needs an MI355X") == 2, (out.stdout + out.stderr)[-2000:]

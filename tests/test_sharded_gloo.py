@@ -14,17 +14,18 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 
-ENV_ID, NUM_ENVS, SEED, STEPS = "GoalContinuous3P-v0", 510, 17, 25
+NUM_ENVS, SEED, STEPS = 510, 17, 25
 
 
 class OracleLocalEngine:
     """Stand-in for the GPU engine with the adapter interface ShardedVectorEnv expects."""
 
-    def __init__(self, env_id, n, seed, env_index_base, max_episode_steps):
+    def __init__(self, env_id, n, seed, env_index_base, max_episode_steps, with_terminal=False):
         from oracle import Oracle
         self.o = Oracle(env_id)
         self.o.params.max_episode_steps = max_episode_steps
         self.n, self.seed, self.base, self.obs_dim = n, seed, env_index_base, self.o.obs_dim
+        self.discrete, self.with_terminal = self.o.discrete, with_terminal
         self.envs = None
 
     def reset_tensors(self):
@@ -32,33 +33,39 @@ class OracleLocalEngine:
         return torch.from_numpy(obs.astype(np.float32))
 
     def step_tensors(self, actions):
-        obs, rew, done, trunc = self.o.vec_step(self.envs, actions.numpy(), seed=self.seed, env_id0=self.base)
-        return (torch.from_numpy(obs.astype(np.float32)), torch.from_numpy(rew.astype(np.float32)),
-                torch.from_numpy(done), torch.from_numpy(trunc))
+        out = self.o.vec_step(self.envs, actions.numpy(), seed=self.seed, env_id0=self.base, want_terminal_obs=self.with_terminal)
+        res = (torch.from_numpy(out[0].astype(np.float32)), torch.from_numpy(out[1].astype(np.float32)),
+               torch.from_numpy(out[2]), torch.from_numpy(out[3]))
+        return res + ((torch.from_numpy(out[4].astype(np.float32)),) if self.with_terminal else ())
 
     def close(self):
         pass
 
 
-def _actions(t):
-    return np.random.default_rng(1000 + t).uniform(-1, 1, size=(NUM_ENVS, 2)).astype(np.float32)
+def _actions(t, discrete=False):
+    rng = np.random.default_rng(1000 + t)
+    return rng.integers(0, 6, NUM_ENVS).astype(np.int32) if discrete else rng.uniform(-1, 1, size=(NUM_ENVS, 2)).astype(np.float32)
 
 
-def _worker(rank, world, port, out_path):
+KEYS = ("obs", "rew", "done", "trunc", "tobs")
+
+
+def _worker(rank, world, port, out_path, env_id, with_terminal):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from space_gym_amd.sharded import ShardedVectorEnv, shard_bounds
     lo, hi = shard_bounds(NUM_ENVS, world, rank)
-    eng = OracleLocalEngine(ENV_ID, hi - lo, SEED, lo, max_episode_steps=12)
-    env = ShardedVectorEnv(ENV_ID, NUM_ENVS, seed=SEED, local_env=eng, device="cpu")
-    assert (env.lo, env.hi) == (lo, hi)
+    eng = OracleLocalEngine(env_id, hi - lo, SEED, lo, max_episode_steps=12, with_terminal=with_terminal)
+    env = ShardedVectorEnv(env_id, NUM_ENVS, seed=SEED, local_env=eng, device="cpu", terminal_observation=with_terminal)
+    assert (env.lo, env.hi) == (lo, hi) and env.discrete == ("Discrete" in env_id)
     trace = [env.reset()]
     for t in range(STEPS):
-        trace.append(env.step(_actions(t) if rank == 0 else None))
+        trace.append(env.step(_actions(t, env.discrete) if rank == 0 else None))
     if rank == 0:
+        assert all(len(step) == (5 if with_terminal else 4) for step in trace[1:])
         np.savez(out_path, reset_obs=trace[0].numpy(), **{f"{k}{t}": v.numpy() for t, step in enumerate(trace[1:])
-                                                      for k, v in zip(("obs", "rew", "done", "trunc"), step)})
+                                                      for k, v in zip(KEYS, step)})
     else:
         assert all(x is None for x in trace)
     dist.barrier()
@@ -71,18 +78,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single_process(world, tmp_path):
+@pytest.mark.parametrize("world,env_id,with_terminal", [(2, "GoalContinuous3P-v0", False), (3, "GoalContinuous3P-v0", True),
+                                                        (2, "GoalDiscrete3-v0", True), (3, "KeplerDiscrete-v0", False)])
+def test_sharded_equals_single_process(world, env_id, with_terminal, tmp_path):
+    """continuous and discrete action specs, with and without terminal observations, equal and ragged shards"""
     out = str(tmp_path / "rank0.npz")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, env_id, with_terminal), nprocs=world, join=True)
     got = np.load(out)
-    ref = OracleLocalEngine(ENV_ID, NUM_ENVS, SEED, 0, max_episode_steps=12)
+    ref = OracleLocalEngine(env_id, NUM_ENVS, SEED, 0, max_episode_steps=12, with_terminal=with_terminal)
     assert np.array_equal(got["reset_obs"], ref.reset_tensors().numpy())
     n_done = 0
     for t in range(STEPS):
-        obs, rew, done, trunc = (x.numpy() for x in ref.step_tensors(torch.from_numpy(_actions(t))))
+        res = [x.numpy() for x in ref.step_tensors(torch.from_numpy(_actions(t, ref.discrete)))]
+        obs, rew, done, trunc = res[:4]
         assert np.array_equal(got[f"obs{t}"], obs) and np.array_equal(got[f"rew{t}"], rew)
         assert np.array_equal(got[f"done{t}"], done) and np.array_equal(got[f"trunc{t}"], trunc)
+        if with_terminal:  # rows of finished envs carry their last observation, the others NaN
+            assert np.array_equal(got[f"tobs{t}"], res[4], equal_nan=True)
+            assert np.isfinite(res[4][done.astype(bool)]).all() and np.isnan(res[4][~done.astype(bool)]).all()
         n_done += int(done.sum())
     assert n_done >= NUM_ENVS  # truncation at 12 steps: every env restarted at least once, on every rank
 
