@@ -162,7 +162,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
-    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B, copy=False)
+    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B, copy=False, terminal_observation=False)
     D = env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
@@ -205,6 +205,16 @@ def main():
             prepared[k]()
             left -= k
 
+    def prepare_steps(n):  # build (and validate) the calls that run_steps(n) will make, outside any timed region
+        left = n
+        while left > 0:
+            k = min(left, chunk)
+            if k not in prepared:
+                prepared[k] = env.prepare_rollout(act_seq[:k], obs[:k], rew[:k], done[:k], trunc[:k])
+            left -= k
+
+    for n in (args.preroll, W, K, min(K, 50)):
+        prepare_steps(n)
     env.reset_torch()
     run_steps(args.preroll)  # set-up: brings the envs to their stationary mix of episode ages and the GPU to its working clocks
     sync_all()
@@ -348,8 +358,9 @@ def main():
                 "kernel_avg_us": u_avg, "kernel_min_us": u_min * 1e3, "kernel_max_us": u_max * 1e3, "launches": u_launches}
         if host_us is not None:
             out["host_numpy_path"] = {"us_per_step": host_us, "value": B / (host_us * 1e-6), "unit": "env-steps/s",
-                                      "what": "sg_step with NumPy arrays in page-locked memory: H2D of the actions, the step "
-                                              "kernel, D2H of obs / reward / done / truncated per step (PCIe-inclusive; never `value`)"}
+                                      "what": "sg_step with NumPy arrays in page-locked memory, no copies on the host side and no "
+                                              "terminal-observation array: H2D of the actions, the step kernel, D2H of obs / reward / done / "
+                                              "truncated per step (PCIe-inclusive; never `value`)"}
         if gather_ms is not None:
             out["ms_per_step_with_rccl_gather"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
