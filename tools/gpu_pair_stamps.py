@@ -14,11 +14,10 @@ import space_gym_amd as sg  # noqa: E402
 from space_gym_amd import _native  # noqa: E402
 
 SLOTS, WAVES = 16, 4096
-PILOT = {0: "top of step (action, ring waits)", 1: "begin: select_initial_step, g(t0)", 2: "RK attempts (+ event records)",
-         3: "state update", 5: "ring record + publish", 12: "prefetch: entry", 13: "prefetch: queue flag", 14: "prefetch: loads issued", 4: "prefetch: exit", 8: "TimeLimit + restart"}
-FIN = {0: "loop", 1: "wait for the pilot", 3: "read record, release slot", 4: "reward + update",
-       6: "refill passes (+ terminal obs)", 7: "restart + fetch next episode", 5: "observe + owner stores",
-       2: "goal resamples + event pass"}
+PILOT = {0: "top of step (action, loop)", 1: "begin: select_initial_step, g(t0)", 2: "RK attempts + event roots",
+         3: "state update", 4: "wait for a ring slot", 5: "ring record + publish", 8: "TimeLimit + restart"}
+FIN = {0: "loop", 1: "wait for the pilot", 3: "read record, event pass, release slot", 4: "reward + update + observe",
+       5: "owner stores", 6: "refill passes", 7: "restart: pop + cold stores + obs", 2: "goal resamples"}
 
 
 def main():
@@ -42,13 +41,11 @@ def main():
     for k, name in PILOT.items():
         print("  %-40s %8.0f" % (name, pil[:, k].mean()))
     print("  %-40s %8.0f" % ("total", sum(pil[:, k].mean() for k in PILOT)))
-    print("  wave-steps with a terminal event %.3f, with a restart %.3f, with an inline episode generation %.4f, with a prefetch %.3f"
-          % (pil[:, 7].mean(), pil[:, 10].mean(), pil[:, 9].mean(), pil[:, 11].mean()))
+    print("  wave-steps with a terminal event %.3f" % pil[:, 7].mean())
     print("finisher waves: cycles per step")
     for k, name in FIN.items():
         print("  %-40s %8.0f" % (name, fin[:, k].mean()))
     print("  %-40s %8.0f" % ("total", sum(fin[:, k].mean() for k in FIN)))
-    print("  refill passes per step %.4f, wave-steps with a goal resample %.3f" % (fin[:, 15].mean(), fin[:, 14].mean()))
 
 
 if __name__ == "__main__":
