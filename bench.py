@@ -162,7 +162,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
-    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B, copy=False, terminal_observation=False)
+    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B, copy=False, terminal_observation=False, validate_actions=False)
     D = env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
@@ -244,6 +244,24 @@ def main():
         sync_all()
         repeats.append(time.perf_counter() - tr)
 
+    # ---- the same K steps again with start/stop events on every dispatch (hipExtLaunchKernelGGL): the kernel's own
+    # duration, as rocprofv3 --kernel-trace reports it.  Straight after the timed regions, on the same clocks (after the
+    # one-launch-per-step passes below the GPU needs ~20 ms of rollout launches to come back to them)
+    launches, kern_ms, kmin, kmax, dt_events = 0, 0.0, 0.0, 0.0, None
+    kernel_name = env.rollout_kernel(min(K, chunk))
+    if timing:
+        run_steps(K)
+        env.set_profiling(True)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(max(1, args.repeats)):
+            run_steps(K)
+        sync_all()
+        dt_events = (time.perf_counter() - t1) / max(1, args.repeats)
+        launches, kern_ms, kmin, kmax = env.get_profile()
+        env.set_profiling(False)
+    env.check_status()
+
     # ---- A/B: the same K steps as K launches of the per-step kernel (what a policy-in-the-loop user gets)
     env.set_unfused_rollout(True)
     step_kernel_name = env.rollout_kernel(1)
@@ -262,23 +280,6 @@ def main():
         u_launches, u_ms, u_min, u_max = env.get_profile()
         env.set_profiling(False)
     env.set_unfused_rollout(False)
-
-    # ---- the same K steps again with start/stop events on every dispatch (hipExtLaunchKernelGGL): the kernel's own
-    # duration, as rocprofv3 --kernel-trace reports it
-    launches, kern_ms, kmin, kmax, dt_events = 0, 0.0, 0.0, 0.0, None
-    kernel_name = env.rollout_kernel(min(K, chunk))
-    if timing:
-        run_steps(K)
-        env.set_profiling(True)
-        sync_all()
-        t1 = time.perf_counter()
-        for _ in range(max(1, args.repeats)):
-            run_steps(K)
-        sync_all()
-        dt_events = (time.perf_counter() - t1) / max(1, args.repeats)
-        launches, kern_ms, kmin, kmax = env.get_profile()
-        env.set_profiling(False)
-    env.check_status()
 
     gather_ms = None
     if args.gather and world > 1:

@@ -57,6 +57,13 @@ typedef struct sg_config {
  * kepler.py:189-231) for num_envs instances on GPU `device`. */
 int sg_create(const sg_config *cfg, int device, sg_env **out);
 int sg_destroy(sg_env *env);
+/* The same for a batch of cfg->num_envs envs cut into contiguous blocks over n_devices GPUs (one handle per device, the
+ * remainder spread over the first ones; env_index_base of block k = cfg->env_index_base + its first env): envs never
+ * interact (gym_space/dynamic_model.py:145-165) and the RNG is keyed by the global env index, so the blocks together are the
+ * same envs as one handle of the whole batch.  handles_out has n_devices entries; on failure none is left allocated.  The
+ * exchange a single-process VectorEnv view needs on top (a rooted gather of obs | reward | done per step) is
+ * space_gym_amd/sharded.py's, over torch.distributed (RCCL). */
+int sg_create_sharded(const sg_config *cfg, int n_devices, const int *devices, sg_env **handles_out);
 const char *sg_last_error(const sg_env *env); /* env may be NULL: last error of a failed sg_create */
 
 int64_t sg_num_envs(const sg_env *env);

@@ -27,6 +27,7 @@ class NativeError(RuntimeError):
 _fp, _u8p, _i32p, _vp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_void_p
 SYMBOLS = {
     "sg_create": (C.c_int, [C.POINTER(SgConfig), C.c_int, C.POINTER(_vp)]),
+    "sg_create_sharded": (C.c_int, [C.POINTER(SgConfig), C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
     "sg_destroy": (C.c_int, [_vp]),
     "sg_last_error": (C.c_char_p, [_vp]),
     "sg_num_envs": (C.c_int64, [_vp]),

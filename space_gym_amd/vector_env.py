@@ -29,9 +29,12 @@ class SpaceGymVectorEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, env_id, num_envs, device=0, seed=0, env_index_base=0, max_episode_steps=None, auto_reset=True,
-                 validate_actions=False, terminal_observation=True, copy=True, steering="velocity"):
+                 validate_actions=True, terminal_observation=True, copy=True, steering="velocity"):
         """steering: "velocity" (ship_steering=1, what every registered id uses) or "acceleration" (ship_steering=0, the
         constructor default of the reference classes: omega is a state, the thruster a torque).
+        validate_actions: step() checks on the host that the actions are in range, as the reference's step asserts
+        (spaceship_env.py:71; discrete ids: ValueError, :201-202); off, out-of-range actions are clamped on the device (the
+        device-tensor calls never validate: that would need a device-to-host synchronisation).
         copy=False: reset()/step() return views of the engine's pinned output buffers, overwritten by the next call
         (no per-step allocation or copy); copy=True returns fresh arrays like gym's vector envs."""
         if env_id not in ENV_SPECS:

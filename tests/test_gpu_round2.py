@@ -339,3 +339,72 @@ def test_sharded_env_on_the_gpu_adapter(env_id):
         sh.close(); ref.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_sg_create_sharded_blocks_equal_one_handle():
+    """sg_create_sharded: contiguous blocks (ragged: 1000 envs over 3 handles, all on this card) with env_index_base set per
+    block reproduce one handle of the whole batch, resets and steps"""
+    import ctypes as C
+    from space_gym_amd import _native
+    lib = _native.load()
+    n, nd = 1000, 3
+    cfg = _native.SgConfig(env_id=b"GoalContinuous3P-v0", num_envs=n, seed=41, env_index_base=500, max_episode_steps=25, auto_reset=1, steering=0)
+    handles = (C.c_void_p * nd)()
+    devs = (C.c_int * nd)(0, 0, 0)
+    assert lib.sg_create_sharded(C.byref(cfg), nd, devs, handles) == 0
+    sizes = [int(lib.sg_num_envs(C.c_void_p(h))) for h in handles]
+    assert sizes == [334, 333, 333]
+    full = make("GoalContinuous3P-v0", n, seed=41, env_index_base=500, max_episode_steps=25)
+    D = full.obs_dim
+    parts = []
+    for h, m in zip(handles, sizes):
+        o = np.empty((m, D), np.float32)
+        assert lib.sg_reset(C.c_void_p(h), o.ctypes.data_as(C.c_void_p)) == 0
+        parts.append(o)
+    assert np.array_equal(np.concatenate(parts), full.reset())
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        of, rf, df, _ = full.step(a)
+        lo, outs = 0, []
+        for h, m in zip(handles, sizes):
+            o, r = np.empty((m, D), np.float32), np.empty(m, np.float32)
+            d, tr = np.empty(m, np.uint8), np.empty(m, np.uint8)
+            ak = np.ascontiguousarray(a[lo:lo + m])
+            assert lib.sg_step(C.c_void_p(h), ak.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                               d.ctypes.data_as(C.c_void_p), tr.ctypes.data_as(C.c_void_p), None) == 0
+            outs.append((o, r, d))
+            lo += m
+        assert np.array_equal(np.concatenate([x[0] for x in outs]), of) and np.array_equal(np.concatenate([x[1] for x in outs]), rf)
+        assert np.array_equal(np.concatenate([x[2] for x in outs]).astype(bool), df)
+    for h in handles:
+        lib.sg_destroy(C.c_void_p(h))
+    bad = (C.c_int * 1)(99)
+    one = (C.c_void_p * 1)()
+    assert lib.sg_create_sharded(C.byref(cfg), 1, bad, one) != 0 and not one[0]
+    full.close()
+
+
+def test_actions_out_of_range_are_rejected_by_default():
+    """the reference's step asserts action_space.contains(raw_action) (spaceship_env.py:71) / raises ValueError for a
+    discrete index out of range (:201-202): the NumPy front end does the same unless validate_actions=False (device clamp)"""
+    n = 256
+    env = make("GoalContinuous2P-v0", n, seed=1)
+    env.reset()
+    a = np.zeros((n, 2), np.float32)
+    a[7, 0] = 1.5
+    with pytest.raises(AssertionError):
+        env.step(a)
+    env.close()
+    env = make("GoalDiscrete2-v0", n, seed=1)
+    env.reset()
+    k = np.zeros(n, np.int32)
+    k[3] = 6
+    with pytest.raises(ValueError):
+        env.step(k)
+    env.close()
+    env = make("GoalContinuous2P-v0", n, seed=1, validate_actions=False)
+    env.reset()
+    obs, rew, done, info = env.step(a)  # clamped into [-1, 1] on the device
+    assert np.isfinite(obs).all() and np.isfinite(rew).all()
+    env.close()
