@@ -129,18 +129,23 @@ def test_reset_distribution_matches_reference_gpu(fam):
 
 
 @pytest.mark.parametrize("env_id,kernel", [("GoalContinuous3P-v0", "pair"), ("GoalContinuous2P-v0", "single"),
-                                           ("KeplerCircleOrbit-v0", "pair"), ("GoalDiscrete4-v0", "pair")])
+                                           ("KeplerCircleOrbit-v0", "pair"), ("GoalDiscrete4-v0", "pair"),
+                                           ("KeplerRandomOrbits-v0", "single"), ("GoalContinuous4P-v0", "unfused")])
 def test_rollout_terminal_observations(env_id, kernel, monkeypatch):
     """sg_rollout_device_terminal: one record per finished env-step with the LAST observation of the episode that ended
     (what the reference's step returns with done=True, spaceship_env.py:75-78), bit-identical to the step kernel's
-    terminal_obs rows; the ordinary outputs are those of sg_rollout_device."""
+    terminal_obs rows; the ordinary outputs are those of sg_rollout_device.  Every plan: the wave-pair and one-wave K-step
+    kernels of both families, and one launch per step with the rows compacted after each."""
     import torch
-    monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", kernel)
+    if kernel != "unfused":
+        monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", kernel)
     n, K = 8192, 160
     gen = torch.Generator(device="cuda").manual_seed(3)
     a = (torch.randint(0, 6, (K, n), device="cuda", generator=gen, dtype=torch.int32) if "Discrete" in env_id
          else torch.rand((K, n, 2), device="cuda", generator=gen) * 2 - 1)
     env = make(env_id, n, seed=6, max_episode_steps=45)
+    env.set_unfused_rollout(kernel == "unfused")
+    assert kernel == "unfused" or (kernel + "_rollout" in env.rollout_kernel(60)) == (kernel == "pair")
     env.reset_torch()
     obs, rew, done, trunc = _rollout_buffers(env, K)
     term = env.terminal_list_torch(capacity=n * K // 4)
