@@ -79,7 +79,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,env_id,with_terminal", [(2, "GoalContinuous3P-v0", False), (3, "GoalContinuous3P-v0", True),
-                                                        (2, "GoalDiscrete3-v0", True), (3, "KeplerDiscrete-v0", False)])
+                                                        (2, "GoalDiscrete3-v0", True), (3, "KeplerDiscrete-v0", False),
+                                                        (8, "GoalContinuous4P-v0", True)])  # config 5's id and rank count
 def test_sharded_equals_single_process(world, env_id, with_terminal, tmp_path):
     """continuous and discrete action specs, with and without terminal observations, equal and ragged shards"""
     out = str(tmp_path / "rank0.npz")
