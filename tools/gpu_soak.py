@@ -10,9 +10,11 @@ import torch
 import space_gym_amd as sg
 from space_gym_amd.registration import ENV_SPECS
 
-B, K, CHUNKS = 65536, 500, int(os.environ.get("SOAK_CHUNKS", "12"))
+B, K, CHUNKS = 65536, int(os.environ.get("SOAK_K", "500")), int(os.environ.get("SOAK_CHUNKS", "12"))
+IDS = [i for i in os.environ.get("SOAK_IDS", "").split(",") if i] or list(ENV_SPECS)  # SOAK_K=20: many short launches (launch boundaries)
 dev = torch.device("cuda", 0)
-for env_id, spec in ENV_SPECS.items():
+for env_id in IDS:
+    spec = ENV_SPECS[env_id]
     os.environ["SPACEGYM_ROLLOUT_KERNEL"] = "single"
     ref = sg.make_vec(env_id, B, seed=11)   # the kernel choice is read when the handle is created
     os.environ.pop("SPACEGYM_ROLLOUT_KERNEL")
