@@ -48,7 +48,7 @@ def test_pair_rollout_matches_oracle_directly(env_id, n, K):
     a_h = a.cpu().numpy()
     for t in range(pre):
         ref_env.step(a_h[t])
-    worst = 0
+    worst = total = 0
     for t in range(K):
         st = ref_env.get_state()
         ob, rw, dn, info = ref_env.step(a_h[t])
@@ -57,7 +57,7 @@ def test_pair_rollout_matches_oracle_directly(env_id, n, K):
         ref = o.step(st["ship"].astype(np.float64), a_h[t], st["planets"].astype(np.float64), st["goal"].astype(np.float64))
         ref_done = ref["done"].astype(bool) | trunc[t].astype(bool)
         same = done[t].astype(bool) == ref_done
-        worst = max(worst, int((~same).sum()))
+        worst, total = max(worst, int((~same).sum())), total + int((~same).sum())
         assert (~same).sum() <= max(2, n // 20000)  # inputs within fp32 rounding of an event boundary
         assert np.abs(last_obs[t][same] - ref["obs"][same]).max() <= TOL_OBS
         rel = np.abs(rew[t][same] - ref["reward"][same]) / np.maximum(1.0, np.abs(ref["reward"][same]))
@@ -65,6 +65,8 @@ def test_pair_rollout_matches_oracle_directly(env_id, n, K):
         # the 7 leading observation slots are the state (x, y, cos, sin, vx, vy, omega)
         s1 = ref["state1"][same]
         assert np.abs(last_obs[t][same][:, [0, 1, 4, 5, 6]] - s1[:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
+    print(f"done-flag disagreements with the oracle: {total} in {n * K} env-steps (worst step {worst})")
+    assert total <= 2  # measured: 0 in 4 194 304 env-steps (an input within fp32 rounding of an event boundary could flip one)
     assert done.sum() > n // 2  # restarts, and with them the event hand-over, were exercised throughout
     ref_env.close()
 
