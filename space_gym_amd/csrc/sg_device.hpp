@@ -75,6 +75,15 @@ SG_FN void sincos_poly(float r, float &s, float &c) {
     c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
 }
 
+// sin/cos for |r| <= 0.36 (weighted minimax fits; 2e-8 / 4e-8 absolute in fp32 arithmetic, i.e. within rounding): the heading
+// advance inside one env-step with Steering.velocity, |5 a1| * step_size <= 0.35.  Beyond the interval the error grows
+// smoothly (2e-7 at 0.45).  7 instructions against 11 for sincos_poly.
+SG_FN void sincos_small(float r, float &s, float &c) {
+    float z = r * r;
+    s = fmaf(r * z, fmaf(z, 8.295134641230106e-3f, -1.666649580001831e-1f), r);
+    c = fmaf(z, fmaf(z, fmaf(z, -1.3838880180093369e-3f, 4.166642666449376e-2f), -0.5f), 1.0f);
+}
+
 // sin/cos for |a| < ~1e3 with a two-term Cody-Waite reduction to [-pi/4, pi/4]
 SG_FN void sincos_acc(float a, float &s, float &c) {
     float k = rintf(a * 0.6366197723675814f);
@@ -146,23 +155,28 @@ struct StepResult {
 // RHS acceleration at displacement (X, Y) from the start position and time t since the step started:
 // thrust -(cos, sin)(theta0 + delta) * F  (dynamic_model.py:168-176) + sum of planet pulls (helpers.py:22-35).
 // cqx/cqy are circle centres relative to the start position; the first NG circles gravitate.
-template <int NC, int NG>
-SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float F, float C0, float S0, float delta,
+// SMALL: |delta| <= 0.36 is known (Steering.velocity), see sincos_small.
+template <int NC, int NG, bool SMALL = false>
+SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float nCF, float nSF, float delta,
                  float X, float Y, float &ax, float &ay) {
     float sd, cd;
-    sincos_poly(delta, sd, cd);  // heading advance since the step started: |delta| <= 6 * 0.07 + 2.5 * 0.07^2
-    float c = fmaf(C0, cd, -S0 * sd), s = fmaf(S0, cd, C0 * sd);
-    ax = -c * F;
-    ay = -s * F;
+    // heading advance since the step started: |delta| <= 5 * 0.07, with Steering.acceleration <= 6 * 0.07 + 2.5 * 0.07^2
+    if (SMALL) sincos_small(delta, sd, cd); else sincos_poly(delta, sd, cd);
+    // thrust -F (cos, sin)(theta0 + delta) with nCF = -F cos theta0, nSF = -F sin theta0 formed once per env-step
+    ax = fmaf(nCF, cd, -(nSF * sd));
+    ay = fmaf(nSF, cd, nCF * sd);
+    // every planet has the same G m (helpers.py:22-35 with one planet mass): G m sum_j d_j / |d_j|^3
+    float sx = 0.0f, sy = 0.0f;
 #pragma unroll
     for (int j = 0; j < NG; j++) {
         float dx = cqx[j] - X, dy = cqy[j] - Y;
         float r2 = fmaf(dx, dx, dy * dy);
         float ir = rsq(r2);
-        float w = gm * ir * ir * ir;
-        ax = fmaf(dx, w, ax);
-        ay = fmaf(dy, w, ay);
+        float w = ir * ir * ir;
+        sx = (j == 0) ? dx * w : fmaf(dx, w, sx);
+        sy = (j == 0) ? dy * w : fmaf(dy, w, sy);
     }
+    if (NG > 0) { ax = fmaf(gm, sx, ax); ay = fmaf(gm, sy, ay); }
 }
 
 // dynamic_model.make_step (dynamic_model.py:94-125) in fp32, as a resumable integrator: begin() does what
@@ -179,8 +193,8 @@ enum : int { kRkContinue = 0, kRkFinished = 1, kRkEvent = 2, kRkEventDeferred = 
 template <int NC, int NG, bool WALLS, bool ACCEL = false>
 struct Integrator {
     // constants of the env-step
-    float t_end, half_world, gm, F, om, alpha, w_limit, x0, y0, C0, S0;  // om: omega at t = 0; alpha: d omega / dt
-    float cax[NC], cay[NC], cR[NC], cqx[NC], cqy[NC];
+    float t_end, half_world, gm, F, om, alpha, w_limit, x0, y0, nCF, nSF;  // om: omega at t = 0; alpha: d omega / dt; nCF, nSF: accel()
+    float cax[NC], cay[NC], cR[NC], cR2[NC], cqx[NC], cqy[NC];
     double cRd[NC];
     float wxp, wyp, wxm, wym;
     // running state
@@ -215,7 +229,7 @@ struct Integrator {
         half_world = half_world_; gm = gm_; F = F_; om = om_; alpha = ACCEL ? alpha_ : 0.0f; w_limit = w_limit_;
         x0 = x0_; y0 = y0_;
 #pragma unroll
-        for (int k = 0; k < NC; k++) { cax[k] = cax_[k]; cay[k] = cay_[k]; cR[k] = cR_[k]; cRd[k] = cRd_[k]; }
+        for (int k = 0; k < NC; k++) { cax[k] = cax_[k]; cay[k] = cay_[k]; cR[k] = cR_[k]; cR2[k] = cR_[k] * cR_[k]; cRd[k] = cRd_[k]; }
         t_end = h_total;
         // circle centres relative to the start position (fp32 working copy; the fp64 root polish uses cax/cay)
 #pragma unroll
@@ -228,13 +242,17 @@ struct Integrator {
                       const float (&cay_)[NC], const float (&cR_)[NC], const double (&cRd_)[NC]) {
         SG_STAMP(8);
         set_constants(h_total, half_world_, gm_, F_, om_, alpha_, w_limit_, x0_, y0_, cax_, cay_, cR_, cRd_);
-        sincos_acc(th0, S0, C0);
+        {
+            float S0, C0;
+            sincos_acc(th0, S0, C0);
+            nCF = -(C0 * F); nSF = -(S0 * F);
+        }
         t = 0.0f; X = 0.0f; Y = 0.0f; vx = vx0; vy = vy0;
         Xd = 0.0; Yd = 0.0;
 
         // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
         k0[0] = vx; k0[1] = vy;
-        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
+        accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
         {
             // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega)
             float sx = fmaf(fabsf(x0), kRtol, kAtol), sy = fmaf(fabsf(y0), kRtol, kAtol);
@@ -251,7 +269,7 @@ struct Integrator {
             // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)
             float ax1, ay1;
             // (Euler probe: theta1 = theta0 + h0 omega, omega1 = omega + h0 alpha)
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, h0 * om, h0 * vx, h0 * vy, ax1, ay1);
+            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, h0 * om, h0 * vx, h0 * vy, ax1, ay1);
             float e0 = h0 * k0[2] * isx, e1 = h0 * k0[3] * isy, e2 = ACCEL ? h0 * alpha * isth : 0.0f, e3 = (ax1 - k0[2]) * isvx,
                   e4 = (ay1 - k0[3]) * isvy;
             float d2 = fsqrt((e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
@@ -262,9 +280,11 @@ struct Integrator {
         }
 
         SG_STAMP(9);
-        // event functions at (t0, y0), ivp.py:646
+        // event functions at (t0, y0), ivp.py:646.  attempt() only needs the SIGN of a circle event |p - c| - R (which events
+        // are active over an accepted step), so it carries |p - c|^2 - R^2: no square root, and |p - c|^2 is what the gravity
+        // term of the stage at that point has formed already.  solve_event() works on the distances themselves.
     #pragma unroll
-        for (int k = 0; k < NC; k++) g[k] = fsqrt(fmaf(cqx[k], cqx[k], cqy[k] * cqy[k])) - cR[k];
+        for (int k = 0; k < NC; k++) g[k] = fmaf(cqx[k], cqx[k], cqy[k] * cqy[k]) - cR2[k];
         if (WALLS) { g[NC] = fminf(wxp, wyp); g[NC + 1] = fminf(wxm, wym); }
 
         rejected = false; n_rk = 0; attempts = 0;
@@ -286,32 +306,41 @@ struct Integrator {
         if (t_new - t_end > 0.0f) t_new = t_end;
         const float h = t_new - t;
         h_abs = h;
+        // heading advance at the stage times t + c h: omega t + c (omega h) when omega is constant
+        const float ph0 = ACCEL ? 0.0f : om * t, phh = ACCEL ? 0.0f : om * h;
+        auto stage_phase = [&](float cc) __attribute__((always_inline)) { return ACCEL ? phase(fmaf(cc, h, t)) : fmaf(cc, phh, ph0); };
+        const float phase_end = ACCEL ? phase(t + h) : ph0 + phh;
         // rk_step (rk.py:14-71); K_s = (vx_s, vy_s, ax_s, ay_s)
+        // sg_j[0..1]: sum_l A_jl a_l of stage j + 1, i.e. (stage velocity - v) / h -- kept for the error estimate below
+        float sg2[2], sg3[2], sg4[2], sg5[2], sg6[2];
         {
             float dvx = A21 * k0[2], dvy = A21 * k0[3];
             k1[0] = fmaf(h, dvx, vx); k1[1] = fmaf(h, dvy, vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C2, h, t)), fmaf(h, A21 * k0[0], X), fmaf(h, A21 * k0[1], Y),
+            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C2), fmaf(h, A21 * k0[0], X), fmaf(h, A21 * k0[1], Y),
                           k1[2], k1[3]);
         }
         {
             float s0 = fmaf(A32, k1[0], A31 * k0[0]), s1 = fmaf(A32, k1[1], A31 * k0[1]);
             float s2 = fmaf(A32, k1[2], A31 * k0[2]), s3 = fmaf(A32, k1[3], A31 * k0[3]);
             k2[0] = fmaf(h, s2, vx); k2[1] = fmaf(h, s3, vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C3, h, t)), fmaf(h, s0, X), fmaf(h, s1, Y), k2[2], k2[3]);
+            sg2[0] = s2; sg2[1] = s3;
+            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C3), fmaf(h, s0, X), fmaf(h, s1, Y), k2[2], k2[3]);
         }
         {
             float s[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) s[i] = fmaf(A43, k2[i], fmaf(A42, k1[i], A41 * k0[i]));
             k3[0] = fmaf(h, s[2], vx); k3[1] = fmaf(h, s[3], vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C4, h, t)), fmaf(h, s[0], X), fmaf(h, s[1], Y), k3[2], k3[3]);
+            sg3[0] = s[2]; sg3[1] = s[3];
+            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C4), fmaf(h, s[0], X), fmaf(h, s[1], Y), k3[2], k3[3]);
         }
         {
             float s[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) s[i] = fmaf(A54, k3[i], fmaf(A53, k2[i], fmaf(A52, k1[i], A51 * k0[i])));
             k4[0] = fmaf(h, s[2], vx); k4[1] = fmaf(h, s[3], vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(fmaf(C5, h, t)), fmaf(h, s[0], X), fmaf(h, s[1], Y), k4[2], k4[3]);
+            sg4[0] = s[2]; sg4[1] = s[3];
+            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C5), fmaf(h, s[0], X), fmaf(h, s[1], Y), k4[2], k4[3]);
         }
         {
             float s[4];
@@ -319,18 +348,18 @@ struct Integrator {
             for (int i = 0; i < 4; i++)
                 s[i] = fmaf(A65, k4[i], fmaf(A64, k3[i], fmaf(A63, k2[i], fmaf(A62, k1[i], A61 * k0[i]))));
             k5[0] = fmaf(h, s[2], vx); k5[1] = fmaf(h, s[3], vy);
-            accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(t + h), fmaf(h, s[0], X), fmaf(h, s[1], Y), k5[2], k5[3]);
+            sg5[0] = s[2]; sg5[1] = s[3];
+            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, phase_end, fmaf(h, s[0], X), fmaf(h, s[1], Y), k5[2], k5[3]);
         }
-        float inc[4];  // y_new - y = h * sum_j B_j K_j
+        // v_new - v = h * sum_j B_j a_j (the position increment is formed in Nystrom form below)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            inc[i] = h * fmaf(B6, k5[i], fmaf(B5, k4[i], fmaf(B4, k3[i], fmaf(B3, k2[i], B1 * k0[i]))));
+        for (int i = 0; i < 2; i++) sg6[i] = fmaf(B6, k5[i + 2], fmaf(B5, k4[i + 2], fmaf(B4, k3[i + 2], fmaf(B3, k2[i + 2], B1 * k0[i + 2]))));
         const float hh = h * h;
         const double Xdn = Xd + ((double)h * (double)vx + (double)(hh * fmaf(BETA5, k4[2], fmaf(BETA4, k3[2], fmaf(BETA3, k2[2], BETA1 * k0[2])))));
         const double Ydn = Yd + ((double)h * (double)vy + (double)(hh * fmaf(BETA5, k4[3], fmaf(BETA4, k3[3], fmaf(BETA3, k2[3], BETA1 * k0[3])))));
-        const float Xn = (float)Xdn, Yn = (float)Ydn, vxn = vx + inc[2], vyn = vy + inc[3];
+        const float Xn = (float)Xdn, Yn = (float)Ydn, vxn = fmaf(h, sg6[0], vx), vyn = fmaf(h, sg6[1], vy);
         k6[0] = vxn; k6[1] = vyn;
-        accel<NC, NG>(cqx, cqy, gm, F, C0, S0, phase(t + h), Xn, Yn, k6[2], k6[3]);  // f_new (FSAL)
+        accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, phase_end, Xn, Yn, k6[2], k6[3]);  // f_new (FSAL)
 
         // error norm over six components; theta and omega contribute exactly zero (sum E = 0, d omega/dt = 0)
         float err2 = 0.0f;
@@ -338,21 +367,25 @@ struct Integrator {
             const float ya[4] = {x0 + X, y0 + Y, vx, vy}, yb[4] = {x0 + Xn, y0 + Yn, vxn, vyn};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                float e = fmaf(E7, k6[i] - k0[i],
-                               fmaf(E6, k5[i] - k0[i], fmaf(E5, k4[i] - k0[i], fmaf(E4, k3[i] - k0[i], E3 * (k2[i] - k0[i])))));
+                // sum_j E_j K_j on differences to stage 1 (sum E = 0).  For the position components K_j = v_j and
+                // v_j - v_1 = h sg_j: the stage sums themselves, without the cancellation of the subtraction.
+                float e = (i < 2) ? h * fmaf(E7, sg6[i & 1], fmaf(E6, sg5[i & 1], fmaf(E5, sg4[i & 1], fmaf(E4, sg3[i & 1], E3 * sg2[i & 1]))))
+                                  : fmaf(E7, k6[i] - k0[i],
+                                         fmaf(E6, k5[i] - k0[i], fmaf(E5, k4[i] - k0[i], fmaf(E4, k3[i] - k0[i], E3 * (k2[i] - k0[i])))));
                 float scale = fmaf(fmaxf(fabsf(ya[i]), fabsf(yb[i])), kRtol, kAtol);
                 float q = e * h * rcp(scale);
                 err2 = fmaf(q, q, err2);
             }
         }
-        const float err = fsqrt(err2 * (1.0f / 6));
+        // err = sqrt(err2 / 6) is only compared with 1 and raised to -1/5 (rk.py:155-168): both from its square
+        const float err = err2 * (1.0f / 6);
         if (!(err < 1.0f)) {  // rejected (also for NaN): shrink and retry
-            h_abs = h * fmaxf(kMinFactor, kSafety * fexp2(-0.2f * flog2(err)));
+            h_abs = h * fmaxf(kMinFactor, kSafety * fexp2(-0.1f * flog2(err)));
             rejected = true;
             if (attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
             return kRkContinue;
         }
-        float factor = (err == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * fexp2(-0.2f * flog2(err)));
+        float factor = (err == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * fexp2(-0.1f * flog2(err)));
         if (rejected) factor = fminf(1.0f, factor);
         rejected = false;
         h_abs = h * factor;
@@ -364,12 +397,20 @@ struct Integrator {
 #pragma unroll
         for (int k = 0; k < NC; k++) {
             float ex = cqx[k] - Xn, ey = cqy[k] - Yn;
-            gn[k] = fsqrt(fmaf(ex, ex, ey * ey)) - cR[k];
+            gn[k] = fmaf(ex, ex, ey * ey) - cR2[k];  // sign of |p - c| - R (see begin())
         }
         if (WALLS) { gn[NC] = fminf(wxp - Xn, wyp - Yn); gn[NC + 1] = fminf(wxm + Xn, wym + Yn); }
+        // sign change or a zero at either end (find_active_events, ivp.py:128-156): g gn <= 0, which is
+        // (g <= 0 && gn >= 0) || (g >= 0 && gn <= 0) as |g| is 0 or >= 1e-8 (no underflow).  The smallest product decides
+        // whether there is any event; which ones is only worked out when there is.
+        float gg[NC + 2], ggmin = 1.0f;
 #pragma unroll
-        for (int k = 0; k < NC + (WALLS ? 2 : 0); k++)  // sign change or a zero at either end (find_active_events, ivp.py:128-156)
-            if (g[k] * gn[k] <= 0.0f) mask |= 1u << k;   // == (g <= 0 && gn >= 0) || (g >= 0 && gn <= 0): |g| is 0 or >= 1e-8, no underflow
+        for (int k = 0; k < NC + (WALLS ? 2 : 0); k++) { gg[k] = g[k] * gn[k]; ggmin = fminf(ggmin, gg[k]); }
+        if (ggmin <= 0.0f) {
+#pragma unroll
+            for (int k = 0; k < NC + (WALLS ? 2 : 0); k++)
+                if (gg[k] <= 0.0f) mask |= 1u << k;
+        }
 
         // angular-velocity event max_abs_vel_angle - |omega| (dynamic_model.py:210-212): only live with Steering.acceleration
         // (|5 a1| <= 5 otherwise); omega is linear in t, so its root is closed-form
@@ -397,7 +438,7 @@ struct Integrator {
                 o.done = 1; o.event = -1; o.n_rk = n_rk;
                 return kRkEventDeferred;
             }
-            solve_event(ev, o, g, gn);
+            solve_event(ev, o);
             return kRkEvent;
         }
 #pragma unroll
@@ -412,29 +453,23 @@ struct Integrator {
 
     // solve_ivp's event handling for an accepted step with sign changes (ivp.py:673-694): the earliest root over the
     // step's 4th-order dense output (rk.py:178-192) becomes the end of the env-step.  Needs set_constants() only.
-    // g0 / g1: the event functions at the two ends of the step when the caller has them (attempt()); null: recomputed.
-    SG_MFN void solve_event(const EventCase &ev, StepResult &o, const float *g0 = nullptr, const float *g1 = nullptr) const {
+    SG_MFN void solve_event(const EventCase &ev, StepResult &o) const {
         const float h = ev.h, t = ev.t, X = ev.X, Y = ev.Y, vx = ev.vx, vy = ev.vy, Xn = ev.Xn, Yn = ev.Yn, s_w = ev.s_w;
         const double Xd = ev.Xd, Yd = ev.Yd;
         const unsigned mask = ev.mask;
         const float(&k0)[4] = ev.k0, (&k2)[4] = ev.k2, (&k3)[4] = ev.k3, (&k4)[4] = ev.k4, (&k5)[4] = ev.k5, (&k6)[4] = ev.k6;
-        // event functions at both ends of the step, by the expressions attempt() / begin() use (X = Y = 0 at t = 0)
+        // event functions at both ends of the step (X = Y = 0 at t = 0); attempt() carries the circles' in squared form
         float g[NC + 2], gn[NC + 2];
-        if (g0) {
 #pragma unroll
-            for (int k = 0; k < NC + 2; k++) { g[k] = g0[k]; gn[k] = g1[k]; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NC; k++) {
-                const float ax_ = cqx[k] - X, ay_ = cqy[k] - Y, bx_ = cqx[k] - Xn, by_ = cqy[k] - Yn;
-                g[k] = fsqrt(fmaf(ax_, ax_, ay_ * ay_)) - cR[k];
-                gn[k] = fsqrt(fmaf(bx_, bx_, by_ * by_)) - cR[k];
-            }
-            g[NC] = g[NC + 1] = gn[NC] = gn[NC + 1] = 1.0f;
-            if (WALLS) {
-                g[NC] = fminf(wxp - X, wyp - Y); g[NC + 1] = fminf(wxm + X, wym + Y);
-                gn[NC] = fminf(wxp - Xn, wyp - Yn); gn[NC + 1] = fminf(wxm + Xn, wym + Yn);
-            }
+        for (int k = 0; k < NC; k++) {
+            const float ax_ = cqx[k] - X, ay_ = cqy[k] - Y, bx_ = cqx[k] - Xn, by_ = cqy[k] - Yn;
+            g[k] = fsqrt(fmaf(ax_, ax_, ay_ * ay_)) - cR[k];
+            gn[k] = fsqrt(fmaf(bx_, bx_, by_ * by_)) - cR[k];
+        }
+        g[NC] = g[NC + 1] = gn[NC] = gn[NC + 1] = 1.0f;
+        if (WALLS) {
+            g[NC] = fminf(wxp - X, wyp - Y); g[NC + 1] = fminf(wxm + X, wym + Y);
+            gn[NC] = fminf(wxp - Xn, wyp - Yn); gn[NC + 1] = fminf(wxm + Xn, wym + Yn);
         }
         // dense output over [t, t_new]: y(s) = y_old + h s (K0 + s (Q1 + s (Q2 + s Q3))), s in [0, 1]
         float q1[4], q2[4], q3[4];
@@ -1089,7 +1124,7 @@ SG_FN void vector_field(const SgDev &c, float x, float y, float th, float vx, fl
 #pragma unroll
     for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x; cqy[k] = cay[k] - y; }
     f[0] = vx; f[1] = vy; f[2] = om0; f[5] = alpha;
-    accel<NC, NG>(cqx, cqy, c.gm, F, C0, S0, 0.0f, 0.0f, 0.0f, f[3], f[4]);
+    accel<NC, NG>(cqx, cqy, c.gm, -(C0 * F), -(S0 * F), 0.0f, 0.0f, 0.0f, f[3], f[4]);
 }
 
 SG_FN Orbit fixed_orbit(const SgDev &c) {
