@@ -159,12 +159,17 @@ struct StepResult {
 template <int NC, int NG, bool SMALL = false>
 SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float nCF, float nSF, float delta,
                  float X, float Y, float &ax, float &ay) {
-    float sd, cd;
-    // heading advance since the step started: |delta| <= 5 * 0.07, with Steering.acceleration <= 6 * 0.07 + 2.5 * 0.07^2
-    if (SMALL) sincos_small(delta, sd, cd); else sincos_poly(delta, sd, cd);
     // thrust -F (cos, sin)(theta0 + delta) with nCF = -F cos theta0, nSF = -F sin theta0 formed once per env-step
-    ax = fmaf(nCF, cd, -(nSF * sd));
-    ay = fmaf(nSF, cd, nCF * sd);
+    if (__builtin_constant_p(delta) && delta == 0.0f) {  // the start of the env-step (products with a literal 0 are not folded)
+        ax = nCF;
+        ay = nSF;
+    } else {
+        float sd, cd;
+        // heading advance since the step started: |delta| <= 5 * 0.07, with Steering.acceleration <= 6 * 0.07 + 2.5 * 0.07^2
+        if (SMALL) sincos_small(delta, sd, cd); else sincos_poly(delta, sd, cd);
+        ax = fmaf(nCF, cd, -(nSF * sd));
+        ay = fmaf(nSF, cd, nCF * sd);
+    }
     // every planet has the same G m (helpers.py:22-35 with one planet mass): G m sum_j d_j / |d_j|^3
     float sx = 0.0f, sy = 0.0f;
 #pragma unroll
@@ -300,6 +305,7 @@ struct Integrator {
         //  attempt budget is spent)
         attempts++;
         float k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
+        k0[0] = vx; k0[1] = vy;  // (always equal: said here so that the pair is not carried twice from attempt to attempt)
         // RungeKutta._step_impl (rk.py:111-176)
         h_abs = fmaxf(h_abs, 1e-9f);
         float t_new = t + h_abs;
@@ -379,13 +385,15 @@ struct Integrator {
         }
         // err = sqrt(err2 / 6) is only compared with 1 and raised to -1/5 (rk.py:155-168): both from its square
         const float err = err2 * (1.0f / 6);
+        // safety * err_norm^(-1/5), once for both outcomes (a wave usually has lanes of either kind); err = 0 gives +inf
+        const float shrink = kSafety * fexp2(-0.1f * flog2(err));
         if (!(err < 1.0f)) {  // rejected (also for NaN): shrink and retry
-            h_abs = h * fmaxf(kMinFactor, kSafety * fexp2(-0.1f * flog2(err)));
+            h_abs = h * fmaxf(kMinFactor, shrink);
             rejected = true;
             if (attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
             return kRkContinue;
         }
-        float factor = (err == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * fexp2(-0.1f * flog2(err)));
+        float factor = fminf(kMaxFactor, shrink);  // (rk.py:166-168: MAX_FACTOR when the error norm is 0)
         if (rejected) factor = fminf(1.0f, factor);
         rejected = false;
         h_abs = h * factor;
