@@ -84,6 +84,39 @@ SG_FN void sincos_small(float r, float &s, float &c) {
     c = fmaf(z, fmaf(z, fmaf(z, -1.3838880180093369e-3f, 4.166642666449376e-2f), -0.5f), 1.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pairs of floats.  On the device a pair is a 64-bit register pair and +, -, *, fma2 are ONE v_pk_* instruction for both
+// halves (measured: the integrator with the compiler's own packing switched off is 8.5 % slower); the integrator below keeps
+// (x, y) pairs -- and pairs of independent scalars where it has them -- in this form.  The host twin (tests) does the same
+// arithmetic element by element: fma2 is a fused multiply-add per half on both sides.
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float f2 __attribute__((ext_vector_type(2)));
+SG_FN f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+SG_FN f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct f2 { float x, y; };
+SG_FN f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+SG_FN f2 operator+(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
+SG_FN f2 operator-(f2 a, f2 b) { return mk2(a.x - b.x, a.y - b.y); }
+SG_FN f2 operator*(f2 a, f2 b) { return mk2(a.x * b.x, a.y * b.y); }
+SG_FN f2 operator*(f2 a, float b) { return mk2(a.x * b, a.y * b); }
+SG_FN f2 operator*(float a, f2 b) { return mk2(a * b.x, a * b.y); }
+SG_FN f2 fma2(f2 a, f2 b, f2 c) { return mk2(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
+#endif
+SG_FN f2 sp2(float a) { return mk2(a, a); }
+SG_FN f2 fma2(float a, f2 b, f2 c) { return fma2(sp2(a), b, c); }
+SG_FN f2 fma2(f2 a, float b, f2 c) { return fma2(a, sp2(b), c); }
+SG_FN f2 fma2(f2 a, float b, float c) { return fma2(a, sp2(b), sp2(c)); }
+SG_FN f2 fma2(f2 a, f2 b, float c) { return fma2(a, b, sp2(c)); }
+
+// sincos_small for two angles at once
+SG_FN void sincos_small2(f2 r, f2 &s, f2 &c) {
+    f2 z = r * r;
+    s = fma2(r * z, fma2(z, 8.295134641230106e-3f, -1.666649580001831e-1f), r);
+    c = fma2(z, fma2(z, fma2(z, -1.3838880180093369e-3f, 4.166642666449376e-2f), -0.5f), 1.0f);
+}
+
 // sin/cos for |a| < ~1e3 with a two-term Cody-Waite reduction to [-pi/4, pi/4]
 SG_FN void sincos_acc(float a, float &s, float &c) {
     float k = rintf(a * 0.6366197723675814f);
@@ -152,36 +185,48 @@ struct StepResult {
     int n_rk;        // accepted RK45 steps (diagnostics)
 };
 
-// RHS acceleration at displacement (X, Y) from the start position and time t since the step started:
-// thrust -(cos, sin)(theta0 + delta) * F  (dynamic_model.py:168-176) + sum of planet pulls (helpers.py:22-35).
-// cqx/cqy are circle centres relative to the start position; the first NG circles gravitate.
-// SMALL: |delta| <= 0.36 is known (Steering.velocity), see sincos_small.
-template <int NC, int NG, bool SMALL = false>
-SG_FN void accel(const float (&cqx)[NC], const float (&cqy)[NC], float gm, float nCF, float nSF, float delta,
-                 float X, float Y, float &ax, float &ay) {
-    // thrust -F (cos, sin)(theta0 + delta) with nCF = -F cos theta0, nSF = -F sin theta0 formed once per env-step
-    if (__builtin_constant_p(delta) && delta == 0.0f) {  // the start of the env-step (products with a literal 0 are not folded)
-        ax = nCF;
-        ay = nSF;
-    } else {
-        float sd, cd;
-        // heading advance since the step started: |delta| <= 5 * 0.07, with Steering.acceleration <= 6 * 0.07 + 2.5 * 0.07^2
-        if (SMALL) sincos_small(delta, sd, cd); else sincos_poly(delta, sd, cd);
-        ax = fmaf(nCF, cd, -(nSF * sd));
-        ay = fmaf(nSF, cd, nCF * sd);
+// RHS acceleration at displacement p = (X, Y) from the start position and heading advance delta since the step started:
+// thrust -(cos, sin)(theta0 + delta) * F  (dynamic_model.py:168-176) + sum of planet pulls (helpers.py:22-35), as
+//   thrust_at(T, Tp, delta) + G m * pull(cq, p)   with  T = -F (cos, sin) theta0,  Tp = T rotated by +90 degrees.
+// cq are the circle centres relative to the start position, as (x, y) pairs; the first NG circles gravitate.
+template <bool SMALL>
+SG_FN f2 thrust_at(f2 T, f2 Tp, float delta) {
+    float sd, cd;
+    // |delta| <= 5 * 0.07 with Steering.velocity (SMALL), <= 6 * 0.07 + 2.5 * 0.07^2 with Steering.acceleration
+    if (SMALL) sincos_small(delta, sd, cd); else sincos_poly(delta, sd, cd);
+    return fma2(T, sp2(cd), Tp * sd);
+}
+// sum_j d_j / |d_j|^3 over the gravitating circles, d_j = c_j - p (every planet has the same G m: one factor for the sum);
+// r2[j] = |d_j|^2 for the caller's event functions.  The cubes of two planets are one packed pair.
+template <int NG>
+SG_FN f2 pull(f2 c0, f2 c1, f2 c2, f2 c3, f2 p, float (&r2)[NG > 0 ? NG : 1]) {
+    static_assert(NG <= 4, "at most four gravitating circles");
+    // (the centres come as named pairs, not as an array: an array of pairs is not split into registers by the compiler)
+    f2 s = mk2(0.0f, 0.0f);
+    if (NG >= 2) {
+        const f2 da = c0 - p, db = c1 - p;
+        const float ra = fmaf(da.x, da.x, da.y * da.y), rb = fmaf(db.x, db.x, db.y * db.y);
+        r2[0] = ra; r2[NG >= 2 ? 1 : 0] = rb;
+        const f2 i = mk2(rsq(ra), rsq(rb));
+        const f2 w = i * i * i;
+        s = fma2(db, sp2(w.y), da * w.x);
     }
-    // every planet has the same G m (helpers.py:22-35 with one planet mass): G m sum_j d_j / |d_j|^3
-    float sx = 0.0f, sy = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NG; j++) {
-        float dx = cqx[j] - X, dy = cqy[j] - Y;
-        float r2 = fmaf(dx, dx, dy * dy);
-        float ir = rsq(r2);
-        float w = ir * ir * ir;
-        sx = (j == 0) ? dx * w : fmaf(dx, w, sx);
-        sy = (j == 0) ? dy * w : fmaf(dy, w, sy);
+    if (NG == 4) {
+        const f2 da = c2 - p, db = c3 - p;
+        const float ra = fmaf(da.x, da.x, da.y * da.y), rb = fmaf(db.x, db.x, db.y * db.y);
+        r2[NG == 4 ? 2 : 0] = ra; r2[NG == 4 ? 3 : 0] = rb;
+        const f2 i = mk2(rsq(ra), rsq(rb));
+        const f2 w = i * i * i;
+        s = fma2(db, sp2(w.y), fma2(da, sp2(w.x), s));
     }
-    if (NG > 0) { ax = fmaf(gm, sx, ax); ay = fmaf(gm, sy, ay); }
+    if (NG & 1) {
+        const f2 dc = (NG == 1 ? c0 : c2) - p;
+        const float rc = fmaf(dc.x, dc.x, dc.y * dc.y), ic = rsq(rc);
+        r2[NG - 1] = rc;
+        const float w = ic * ic * ic;
+        s = (NG == 1) ? dc * w : fma2(dc, sp2(w), s);
+    }
+    return s;
 }
 
 // dynamic_model.make_step (dynamic_model.py:94-125) in fp32, as a resumable integrator: begin() does what
@@ -199,7 +244,9 @@ template <int NC, int NG, bool WALLS, bool ACCEL = false>
 struct Integrator {
     // constants of the env-step
     float t_end, half_world, gm, F, om, alpha, w_limit, x0, y0, nCF, nSF;  // om: omega at t = 0; alpha: d omega / dt; nCF, nSF: accel()
-    float cax[NC], cay[NC], cR[NC], cR2[NC], cqx[NC], cqy[NC];
+    float cax[NC], cay[NC], cR[NC], cR2[NC];
+    f2 cq0, cq1, cq2, cq3;  // centres relative to the start position, (x, y) pairs (named: see pull())
+    SG_MFN f2 cq_at(int k) const { return k == 0 ? cq0 : k == 1 ? cq1 : k == 2 ? cq2 : cq3; }
     double cRd[NC];
     float wxp, wyp, wxm, wym;
     // running state
@@ -237,8 +284,20 @@ struct Integrator {
         for (int k = 0; k < NC; k++) { cax[k] = cax_[k]; cay[k] = cay_[k]; cR[k] = cR_[k]; cR2[k] = cR_[k] * cR_[k]; cRd[k] = cRd_[k]; }
         t_end = h_total;
         // circle centres relative to the start position (fp32 working copy; the fp64 root polish uses cax/cay)
+        {
+            float rx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ry[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x0; cqy[k] = cay[k] - y0; }
+            for (int k = 0; k < NC; k++) {
+                rx[k] = cax_[k]; ry[k] = cay_[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+                // (opaque scalars: left alone, the compiler pairs the centres' x's of two planets straight out of the caller's
+                //  arrays and then transposes to (x, y) pairs through memory)
+                asm volatile("" : "+v"(rx[k]), "+v"(ry[k]));
+#endif
+            }
+            const f2 o = mk2(x0, y0);
+            cq0 = mk2(rx[0], ry[0]) - o; cq1 = mk2(rx[1], ry[1]) - o; cq2 = mk2(rx[2], ry[2]) - o; cq3 = mk2(rx[3], ry[3]) - o;
+        }
         wxp = half_world - x0; wyp = half_world - y0; wxm = half_world + x0; wym = half_world + y0;
     }
 
@@ -254,33 +313,45 @@ struct Integrator {
         }
         t = 0.0f; X = 0.0f; Y = 0.0f; vx = vx0; vy = vy0;
         Xd = 0.0; Yd = 0.0;
+        const f2 T = mk2(nCF, nSF), Tp = mk2(-nSF, nCF), V = mk2(vx, vy);
 
         // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
-        k0[0] = vx; k0[1] = vy;
-        accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, 0.0f, 0.0f, 0.0f, k0[2], k0[3]);
+        float r2s[NG > 0 ? NG : 1];  // |p - c_j|^2 at the start
+        f2 origin = mk2(0.0f, 0.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (opaque: with a literal 0 the compiler pairs the squared distances of two planets instead of (x, y) of one and
+        //  transposes the centres through memory for it)
+        asm volatile("" : "+v"(origin));
+#endif
+        const f2 a0 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, origin, r2s), T);  // (heading advance 0: the thrust is T itself)
+        k0[0] = vx; k0[1] = vy; k0[2] = a0.x; k0[3] = a0.y;
         {
-            // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega)
-            float sx = fmaf(fabsf(x0), kRtol, kAtol), sy = fmaf(fabsf(y0), kRtol, kAtol);
-            float sth = fmaf(fabsf(th0), kRtol, kAtol), som = fmaf(fabsf(om), kRtol, kAtol);
-            float svx = fmaf(fabsf(vx), kRtol, kAtol), svy = fmaf(fabsf(vy), kRtol, kAtol);
-            float isx = rcp(sx), isy = rcp(sy), isth = rcp(sth), isom = rcp(som), isvx = rcp(svx), isvy = rcp(svy);
-            float a0 = x0 * isx, a1 = y0 * isy, a2 = th0 * isth, a3 = vx * isvx, a4 = vy * isvy, a5 = om * isom;
-            float d0 = fsqrt((a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5) * (1.0f / 6));
+            // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega), as the pairs (x, y), (vx, vy)
+            // and the two scalars theta, omega
+            const f2 is_p = mk2(rcp(fmaf(fabsf(x0), kRtol, kAtol)), rcp(fmaf(fabsf(y0), kRtol, kAtol)));
+            const f2 is_v = mk2(rcp(fmaf(fabsf(vx), kRtol, kAtol)), rcp(fmaf(fabsf(vy), kRtol, kAtol)));
+            const float isth = rcp(fmaf(fabsf(th0), kRtol, kAtol)), isom = rcp(fmaf(fabsf(om), kRtol, kAtol));
+            const f2 y_p = mk2(x0, y0) * is_p, y_v = V * is_v;
+            const float y_th = th0 * isth, y_om = om * isom;
+            const f2 n0 = fma2(y_v, y_v, y_p * y_p);
+            const float d0 = fsqrt(fmaf(y_om, y_om, fmaf(y_th, y_th, n0.x + n0.y)) * (1.0f / 6));
             // f0 = (vx, vy, omega, ax, ay, alpha)
-            float b0 = vx * isx, b1 = vy * isy, b2 = om * isth, b3 = k0[2] * isvx, b4 = k0[3] * isvy, b5 = ACCEL ? alpha * isom : 0.0f;
-            float d1 = fsqrt((b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4 + b5 * b5) * (1.0f / 6));
+            const f2 f_p = V * is_p, f_v = a0 * is_v;
+            const float f_th = om * isth, f_om = ACCEL ? alpha * isom : 0.0f;
+            const f2 n1 = fma2(f_v, f_v, f_p * f_p);
+            const float d1 = fsqrt(fmaf(f_om, f_om, fmaf(f_th, f_th, n1.x + n1.y)) * (1.0f / 6));
             float h0 = (fminf(d0, d1) < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);  // d0 < 1e-5 or d1 < 1e-5 (common.py:96-99)
             h0 = fminf(h0, t_end);
-            // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)
-            float ax1, ay1;
-            // (Euler probe: theta1 = theta0 + h0 omega, omega1 = omega + h0 alpha)
-            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, h0 * om, h0 * vx, h0 * vy, ax1, ay1);
-            float e0 = h0 * k0[2] * isx, e1 = h0 * k0[3] * isy, e2 = ACCEL ? h0 * alpha * isth : 0.0f, e3 = (ax1 - k0[2]) * isvx,
-                  e4 = (ay1 - k0[3]) * isvy;
-            float d2 = fsqrt((e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3 + e4 * e4) * (1.0f / 6)) * rcp(h0);
-            float dm = fmaxf(d1, d2);
-            float h1 = (dm <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
-                                                       : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
+            // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)   (Euler probe: theta1 = theta0 + h0 omega, omega1 = omega + h0 alpha)
+            float r2p[NG > 0 ? NG : 1];
+            const f2 a1 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, V * h0, r2p), thrust_at<!ACCEL>(T, Tp, h0 * om));
+            const f2 e_p = (a0 * h0) * is_p, e_v = (a1 - a0) * is_v;
+            const float e_th = ACCEL ? h0 * alpha * isth : 0.0f;
+            const f2 n2 = fma2(e_v, e_v, e_p * e_p);
+            const float d2 = fsqrt(fmaf(e_th, e_th, n2.x + n2.y) * (1.0f / 6)) * rcp(h0);
+            const float dm = fmaxf(d1, d2);
+            const float h1 = (dm <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
+                                            : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
             h_abs = fminf(fminf(100.0f * h0, h1), t_end);
         }
 
@@ -289,7 +360,9 @@ struct Integrator {
         // are active over an accepted step), so it carries |p - c|^2 - R^2: no square root, and |p - c|^2 is what the gravity
         // term of the stage at that point has formed already.  solve_event() works on the distances themselves.
     #pragma unroll
-        for (int k = 0; k < NC; k++) g[k] = fmaf(cqx[k], cqx[k], cqy[k] * cqy[k]) - cR2[k];
+        for (int k = 0; k < NG; k++) g[k] = r2s[k] - cR2[k];
+    #pragma unroll
+        for (int k = NG; k < NC; k++) { const f2 c = cq_at(k); g[k] = fmaf(c.x, c.x, c.y * c.y) - cR2[k]; }
         if (WALLS) { g[NC] = fminf(wxp, wyp); g[NC + 1] = fminf(wxm, wym); }
 
         rejected = false; n_rk = 0; attempts = 0;
@@ -304,84 +377,73 @@ struct Integrator {
         // (t < t_end holds on entry: begin() starts at t = 0 and the exits below leave the loop once t_end is reached or the
         //  attempt budget is spent)
         attempts++;
-        float k1[4], k2[4], k3[4], k4[4], k5[4], k6[4];
-        k0[0] = vx; k0[1] = vy;  // (always equal: said here so that the pair is not carried twice from attempt to attempt)
         // RungeKutta._step_impl (rk.py:111-176)
         h_abs = fmaxf(h_abs, 1e-9f);
         float t_new = t + h_abs;
         if (t_new - t_end > 0.0f) t_new = t_end;
         const float h = t_new - t;
         h_abs = h;
-        // heading advance at the stage times t + c h: omega t + c (omega h) when omega is constant
-        const float ph0 = ACCEL ? 0.0f : om * t, phh = ACCEL ? 0.0f : om * h;
-        auto stage_phase = [&](float cc) __attribute__((always_inline)) { return ACCEL ? phase(fmaf(cc, h, t)) : fmaf(cc, phh, ph0); };
-        const float phase_end = ACCEL ? phase(t + h) : ph0 + phh;
-        // rk_step (rk.py:14-71); K_s = (vx_s, vy_s, ax_s, ay_s)
-        // sg_j[0..1]: sum_l A_jl a_l of stage j + 1, i.e. (stage velocity - v) / h -- kept for the error estimate below
-        float sg2[2], sg3[2], sg4[2], sg5[2], sg6[2];
+        const f2 V = mk2(vx, vy), P = mk2(X, Y), a0 = mk2(k0[2], k0[3]);  // K_1 = (V, a0): velocity and acceleration at t (FSAL)
+        // Thrust at the stage times t + c h (stage 6 and the FSAL stage share t + h).  With Steering.velocity the heading
+        // advance is omega (t + c h) = omega t + c (omega h) and small: the five sines and cosines are two packed pairs and one.
+        f2 th1, th2, th3, th4, th5;
         {
-            float dvx = A21 * k0[2], dvy = A21 * k0[3];
-            k1[0] = fmaf(h, dvx, vx); k1[1] = fmaf(h, dvy, vy);
-            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C2), fmaf(h, A21 * k0[0], X), fmaf(h, A21 * k0[1], Y),
-                          k1[2], k1[3]);
-        }
-        {
-            float s0 = fmaf(A32, k1[0], A31 * k0[0]), s1 = fmaf(A32, k1[1], A31 * k0[1]);
-            float s2 = fmaf(A32, k1[2], A31 * k0[2]), s3 = fmaf(A32, k1[3], A31 * k0[3]);
-            k2[0] = fmaf(h, s2, vx); k2[1] = fmaf(h, s3, vy);
-            sg2[0] = s2; sg2[1] = s3;
-            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C3), fmaf(h, s0, X), fmaf(h, s1, Y), k2[2], k2[3]);
-        }
-        {
-            float s[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) s[i] = fmaf(A43, k2[i], fmaf(A42, k1[i], A41 * k0[i]));
-            k3[0] = fmaf(h, s[2], vx); k3[1] = fmaf(h, s[3], vy);
-            sg3[0] = s[2]; sg3[1] = s[3];
-            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C4), fmaf(h, s[0], X), fmaf(h, s[1], Y), k3[2], k3[3]);
-        }
-        {
-            float s[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) s[i] = fmaf(A54, k3[i], fmaf(A53, k2[i], fmaf(A52, k1[i], A51 * k0[i])));
-            k4[0] = fmaf(h, s[2], vx); k4[1] = fmaf(h, s[3], vy);
-            sg4[0] = s[2]; sg4[1] = s[3];
-            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, stage_phase(C5), fmaf(h, s[0], X), fmaf(h, s[1], Y), k4[2], k4[3]);
-        }
-        {
-            float s[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                s[i] = fmaf(A65, k4[i], fmaf(A64, k3[i], fmaf(A63, k2[i], fmaf(A62, k1[i], A61 * k0[i]))));
-            k5[0] = fmaf(h, s[2], vx); k5[1] = fmaf(h, s[3], vy);
-            sg5[0] = s[2]; sg5[1] = s[3];
-            accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, phase_end, fmaf(h, s[0], X), fmaf(h, s[1], Y), k5[2], k5[3]);
-        }
-        // v_new - v = h * sum_j B_j a_j (the position increment is formed in Nystrom form below)
-#pragma unroll
-        for (int i = 0; i < 2; i++) sg6[i] = fmaf(B6, k5[i + 2], fmaf(B5, k4[i + 2], fmaf(B4, k3[i + 2], fmaf(B3, k2[i + 2], B1 * k0[i + 2]))));
-        const float hh = h * h;
-        const double Xdn = Xd + ((double)h * (double)vx + (double)(hh * fmaf(BETA5, k4[2], fmaf(BETA4, k3[2], fmaf(BETA3, k2[2], BETA1 * k0[2])))));
-        const double Ydn = Yd + ((double)h * (double)vy + (double)(hh * fmaf(BETA5, k4[3], fmaf(BETA4, k3[3], fmaf(BETA3, k2[3], BETA1 * k0[3])))));
-        const float Xn = (float)Xdn, Yn = (float)Ydn, vxn = fmaf(h, sg6[0], vx), vyn = fmaf(h, sg6[1], vy);
-        k6[0] = vxn; k6[1] = vyn;
-        accel<NC, NG, !ACCEL>(cqx, cqy, gm, nCF, nSF, phase_end, Xn, Yn, k6[2], k6[3]);  // f_new (FSAL)
-
-        // error norm over six components; theta and omega contribute exactly zero (sum E = 0, d omega/dt = 0)
-        float err2 = 0.0f;
-        {
-            const float ya[4] = {x0 + X, y0 + Y, vx, vy}, yb[4] = {x0 + Xn, y0 + Yn, vxn, vyn};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                // sum_j E_j K_j on differences to stage 1 (sum E = 0).  For the position components K_j = v_j and
-                // v_j - v_1 = h sg_j: the stage sums themselves, without the cancellation of the subtraction.
-                float e = (i < 2) ? h * fmaf(E7, sg6[i & 1], fmaf(E6, sg5[i & 1], fmaf(E5, sg4[i & 1], fmaf(E4, sg3[i & 1], E3 * sg2[i & 1]))))
-                                  : fmaf(E7, k6[i] - k0[i],
-                                         fmaf(E6, k5[i] - k0[i], fmaf(E5, k4[i] - k0[i], fmaf(E4, k3[i] - k0[i], E3 * (k2[i] - k0[i])))));
-                float scale = fmaf(fmaxf(fabsf(ya[i]), fabsf(yb[i])), kRtol, kAtol);
-                float q = e * h * rcp(scale);
-                err2 = fmaf(q, q, err2);
+            const f2 T = mk2(nCF, nSF), Tp = mk2(-nSF, nCF);
+            if (ACCEL) {
+                th1 = thrust_at<false>(T, Tp, phase(fmaf(C2, h, t))); th2 = thrust_at<false>(T, Tp, phase(fmaf(C3, h, t)));
+                th3 = thrust_at<false>(T, Tp, phase(fmaf(C4, h, t))); th4 = thrust_at<false>(T, Tp, phase(fmaf(C5, h, t)));
+                th5 = thrust_at<false>(T, Tp, phase(t + h));
+            } else {
+                const float ph0 = om * t, phh = om * h;
+                f2 s12, c12, s34, c34;
+                sincos_small2(fma2(mk2(C2, C3), phh, ph0), s12, c12);
+                sincos_small2(fma2(mk2(C4, C5), phh, ph0), s34, c34);
+                th1 = fma2(T, sp2(c12.x), Tp * s12.x); th2 = fma2(T, sp2(c12.y), Tp * s12.y);
+                th3 = fma2(T, sp2(c34.x), Tp * s34.x); th4 = fma2(T, sp2(c34.y), Tp * s34.y);
+                th5 = thrust_at<true>(T, Tp, ph0 + phh);
             }
+        }
+        // rk_step (rk.py:14-71); K_s = (v_s, a_s) as two pairs.  sa_s = sum_l A_sl a_l, i.e. (v_s - V) / h: kept for the
+        // error estimate below.
+        float r2x[NG > 0 ? NG : 1], r2n[NG > 0 ? NG : 1];
+        const f2 sa1 = a0 * A21;
+        const f2 v1 = fma2(h, sa1, V);
+        const f2 a1 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, V * A21, P), r2x), th1);
+        const f2 sa2 = fma2(A32, a1, a0 * A31);
+        const f2 v2 = fma2(h, sa2, V);
+        const f2 a2 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A32, v1, V * A31), P), r2x), th2);
+        const f2 sa3 = fma2(A43, a2, fma2(A42, a1, a0 * A41));
+        const f2 v3 = fma2(h, sa3, V);
+        const f2 a3 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A43, v2, fma2(A42, v1, V * A41)), P), r2x), th3);
+        const f2 sa4 = fma2(A54, a3, fma2(A53, a2, fma2(A52, a1, a0 * A51)));
+        const f2 v4 = fma2(h, sa4, V);
+        const f2 a4 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A54, v3, fma2(A53, v2, fma2(A52, v1, V * A51))), P), r2x), th4);
+        const f2 sa5 = fma2(A65, a4, fma2(A64, a3, fma2(A63, a2, fma2(A62, a1, a0 * A61))));
+        const f2 v5 = fma2(h, sa5, V);
+        const f2 a5 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A65, v4, fma2(A64, v3, fma2(A63, v2, fma2(A62, v1, V * A61)))), P), r2x), th5);
+        // v_new - v = h * sum_j B_j a_j; the position increment in Nystrom form, h v + h^2 sum_l beta_l a_l, accumulated in fp64
+        const f2 sa6 = fma2(B6, a5, fma2(B5, a4, fma2(B4, a3, fma2(B3, a2, a0 * B1))));
+        const f2 nys = fma2(BETA5, a4, fma2(BETA4, a3, fma2(BETA3, a2, a0 * BETA1))) * (h * h);
+        const double Xdn = Xd + ((double)h * (double)vx + (double)nys.x);
+        const double Ydn = Yd + ((double)h * (double)vy + (double)nys.y);
+        const float Xn = (float)Xdn, Yn = (float)Ydn;
+        const f2 Pn = mk2(Xn, Yn), v6 = fma2(h, sa6, V);
+        const float vxn = v6.x, vyn = v6.y;
+        const f2 a6 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, Pn, r2n), th5);  // f_new (FSAL)
+
+        // error norm over six components; theta and omega contribute exactly zero (sum E = 0, d omega/dt = 0).
+        // sum_j E_j K_j on differences to stage 1 (sum E = 0); for the position components K_j = v_j and v_j - V = h sa_j:
+        // the stage sums themselves, without the cancellation of a subtraction.
+        float err2;
+        {
+            const f2 e_p = fma2(E7, sa6, fma2(E6, sa5, fma2(E5, sa4, fma2(E4, sa3, sa2 * E3)))) * h;
+            const f2 e_v = fma2(E7, a6 - a0, fma2(E6, a5 - a0, fma2(E5, a4 - a0, fma2(E4, a3 - a0, (a2 - a0) * E3))));
+            const f2 p0 = mk2(x0, y0) + P, p1 = mk2(x0, y0) + Pn;
+            const f2 sc_p = fma2(mk2(fmaxf(fabsf(p0.x), fabsf(p1.x)), fmaxf(fabsf(p0.y), fabsf(p1.y))), kRtol, kAtol);
+            const f2 sc_v = fma2(mk2(fmaxf(fabsf(vx), fabsf(vxn)), fmaxf(fabsf(vy), fabsf(vyn))), kRtol, kAtol);
+            const f2 q_p = (e_p * h) * mk2(rcp(sc_p.x), rcp(sc_p.y)), q_v = (e_v * h) * mk2(rcp(sc_v.x), rcp(sc_v.y));
+            const f2 n = fma2(q_v, q_v, q_p * q_p);
+            err2 = n.x + n.y;
         }
         // err = sqrt(err2 / 6) is only compared with 1 and raised to -1/5 (rk.py:155-168): both from its square
         const float err = err2 * (1.0f / 6);
@@ -402,10 +464,14 @@ struct Integrator {
         // events over this accepted step (ivp.py:673-694, find_active_events with direction 0)
         float gn[NC + 2];
         unsigned mask = 0;
+        // sign of |p - c| - R (see begin()); the gravitating circles' |p - c|^2 is the FSAL stage's
 #pragma unroll
-        for (int k = 0; k < NC; k++) {
-            float ex = cqx[k] - Xn, ey = cqy[k] - Yn;
-            gn[k] = fmaf(ex, ex, ey * ey) - cR2[k];  // sign of |p - c| - R (see begin())
+        for (int k = 0; k < NG; k++) gn[k] = r2n[k] - cR2[k];
+#pragma unroll
+        for (int k = NG; k < NC; k++) {
+            const f2 c = cq_at(k);
+            float ex = c.x - Xn, ey = c.y - Yn;
+            gn[k] = fmaf(ex, ex, ey * ey) - cR2[k];
         }
         if (WALLS) { gn[NC] = fminf(wxp - Xn, wyp - Yn); gn[NC + 1] = fminf(wxm + Xn, wym + Yn); }
         // sign change or a zero at either end (find_active_events, ivp.py:128-156): g gn <= 0, which is
@@ -439,7 +505,12 @@ struct Integrator {
             EventCase ev;
             ev.h = h; ev.t = t; ev.X = X; ev.Y = Y; ev.vx = vx; ev.vy = vy; ev.Xn = Xn; ev.Yn = Yn; ev.Xd = Xd; ev.Yd = Yd;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { ev.k0[i] = k0[i]; ev.k2[i] = k2[i]; ev.k3[i] = k3[i]; ev.k4[i] = k4[i]; ev.k5[i] = k5[i]; ev.k6[i] = k6[i]; }
+            for (int i = 0; i < 2; i++) {
+                ev.k0[i] = i ? V.y : V.x; ev.k2[i] = i ? v2.y : v2.x; ev.k3[i] = i ? v3.y : v3.x; ev.k4[i] = i ? v4.y : v4.x;
+                ev.k5[i] = i ? v5.y : v5.x; ev.k6[i] = i ? v6.y : v6.x;
+                ev.k0[i + 2] = i ? a0.y : a0.x; ev.k2[i + 2] = i ? a2.y : a2.x; ev.k3[i + 2] = i ? a3.y : a3.x;
+                ev.k4[i + 2] = i ? a4.y : a4.x; ev.k5[i + 2] = i ? a5.y : a5.x; ev.k6[i + 2] = i ? a6.y : a6.x;
+            }
             ev.mask = mask; ev.s_w = s_w; ev.n_rk = n_rk;
             if (sink(ev)) {
                 o.dXd = 0.0; o.dYd = 0.0; o.dX = 0.0f; o.dY = 0.0f; o.vx = 0.0f; o.vy = 0.0f; o.t = t; o.dth = 0.0f; o.om = om;
@@ -453,8 +524,7 @@ struct Integrator {
         for (int k = 0; k < NC + (WALLS ? 2 : 0); k++) g[k] = gn[k];
         if (attempts == 1) { SG_STAMP(10); }
         t = t_new; X = Xn; Y = Yn; Xd = Xdn; Yd = Ydn; vx = vxn; vy = vyn;
-#pragma unroll
-        for (int i = 0; i < 4; i++) k0[i] = k6[i];
+        k0[0] = vxn; k0[1] = vyn; k0[2] = a6.x; k0[3] = a6.y;
         if (!(t < t_end) || attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
         return kRkContinue;
     }
@@ -470,7 +540,8 @@ struct Integrator {
         float g[NC + 2], gn[NC + 2];
 #pragma unroll
         for (int k = 0; k < NC; k++) {
-            const float ax_ = cqx[k] - X, ay_ = cqy[k] - Y, bx_ = cqx[k] - Xn, by_ = cqy[k] - Yn;
+            const f2 c = cq_at(k);
+            const float ax_ = c.x - X, ay_ = c.y - Y, bx_ = c.x - Xn, by_ = c.y - Yn;
             g[k] = fsqrt(fmaf(ax_, ax_, ay_ * ay_)) - cR[k];
             gn[k] = fsqrt(fmaf(bx_, bx_, by_ * by_)) - cR[k];
         }
@@ -511,7 +582,7 @@ struct Integrator {
             for (int j = 0; j < NC + (WALLS ? 2 : 0); j++)
                 if (j == k) {
                     g0 = g[j]; g1 = gn[j];
-                    if (j < NC) { ecx = cqx[j]; ecy = cqy[j]; eR = cR[j]; eax = cax[j]; eay = cay[j]; eRd = cRd[j]; }
+                    if (j < NC) { const f2 c = cq_at(j); ecx = c.x; ecy = c.y; eR = cR[j]; eax = cax[j]; eay = cay[j]; eRd = cRd[j]; }
                 }
             const bool circle = k < NC, leaving = g0 > 0.0f;
             const float sgn = (k == NC) ? 1.0f : -1.0f;                      // world_max : world_min
@@ -1125,14 +1196,18 @@ SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, floa
 template <int NC, int NG, bool ACCEL>
 SG_FN void vector_field(const SgDev &c, float x, float y, float th, float vx, float vy, float om_state, float a0, float a1,
                         const float (&cax)[NC], const float (&cay)[NC], float (&f)[6]) {
-    float engine, F, om, om0, alpha, S0, C0, cqx[NC], cqy[NC];
+    float engine, F, om, om0, alpha, S0, C0;
+    static_assert(NC <= 4, "at most four circles");
     translate_action(a0, a1, c.max_engine_force, engine, F, om);
     steering<ACCEL>(c, a1, om, om_state, om0, alpha);
     sincos_acc(th, S0, C0);
-#pragma unroll
-    for (int k = 0; k < NC; k++) { cqx[k] = cax[k] - x; cqy[k] = cay[k] - y; }
+    const f2 o = mk2(x, y);
+    const f2 cq0 = mk2(cax[0], cay[0]) - o, cq1 = mk2(cax[NC > 1 ? 1 : 0], cay[NC > 1 ? 1 : 0]) - o,
+             cq2 = mk2(cax[NC > 2 ? 2 : 0], cay[NC > 2 ? 2 : 0]) - o, cq3 = mk2(cax[NC > 3 ? 3 : 0], cay[NC > 3 ? 3 : 0]) - o;
     f[0] = vx; f[1] = vy; f[2] = om0; f[5] = alpha;
-    accel<NC, NG>(cqx, cqy, c.gm, -(C0 * F), -(S0 * F), 0.0f, 0.0f, 0.0f, f[3], f[4]);
+    float r2[NG > 0 ? NG : 1];
+    const f2 a = fma2(c.gm, pull<NG>(cq0, cq1, cq2, cq3, mk2(0.0f, 0.0f), r2), mk2(-(C0 * F), -(S0 * F)));
+    f[3] = a.x; f[4] = a.y;
 }
 
 SG_FN Orbit fixed_orbit(const SgDev &c) {
