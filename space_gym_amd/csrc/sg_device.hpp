@@ -368,7 +368,8 @@ struct Integrator {
         rejected = false; n_rk = 0; attempts = 0;
     }
 
-    // One RK attempt.  Returns kRkContinue, or fills `o` and returns kRkFinished / kRkEvent.
+    // One RK attempt.  Returns kRkContinue, kRkFinished (the caller then takes the result with finish(): run() below), or
+    // fills `o` and returns kRkEvent / kRkEventDeferred.
     // `sink(ev)`: called for an accepted step with an event before it is solved; if it returns true the case has been taken
     // over (o.done = 1, return value kRkEventDeferred), else it is solved here.
     struct NoSink { SG_MFN bool operator()(const EventCase &) const { return false; } };
@@ -452,7 +453,7 @@ struct Integrator {
         if (!(err < 1.0f)) {  // rejected (also for NaN): shrink and retry
             h_abs = h * fmaxf(kMinFactor, shrink);
             rejected = true;
-            if (attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
+            if (attempts >= kMaxRkAttempts) return kRkFinished;
             return kRkContinue;
         }
         float factor = fminf(kMaxFactor, shrink);  // (rk.py:166-168: MAX_FACTOR when the error norm is 0)
@@ -520,13 +521,22 @@ struct Integrator {
             solve_event(ev, o);
             return kRkEvent;
         }
-#pragma unroll
-        for (int k = 0; k < NC + (WALLS ? 2 : 0); k++) g[k] = gn[k];
+        // (g keeps its values from the start of the env-step: a lane that goes on has seen no sign change and no zero, so every
+        //  g_k still has the sign it started with, and only that sign enters the test above)
         if (attempts == 1) { SG_STAMP(10); }
         t = t_new; X = Xn; Y = Yn; Xd = Xdn; Yd = Ydn; vx = vxn; vy = vyn;
         k0[0] = vxn; k0[1] = vyn; k0[2] = a6.x; k0[3] = a6.y;
-        if (!(t < t_end) || attempts >= kMaxRkAttempts) { finish(o); return kRkFinished; }
+        if (!(t < t_end) || attempts >= kMaxRkAttempts) return kRkFinished;
         return kRkContinue;
+    }
+
+    // All attempts of one env-step.  The result of a lane that reaches the end of the step is read out of the integrator once,
+    // after the loop, not in whichever pass of the loop the lane happens to finish.
+    template <typename SINK = NoSink>
+    SG_MFN void run(StepResult &o, SINK &&sink = NoSink()) {
+        int status;
+        while ((status = attempt(o, sink)) == kRkContinue) {}
+        if (status == kRkFinished) finish(o);
     }
 
     // solve_ivp's event handling for an accepted step with sign changes (ivp.py:673-694): the earliest root over the
@@ -685,7 +695,7 @@ SG_FN void make_step(float h_total, float half_world, float gm, float F, float o
                      const float (&cR)[NC], const double (&cRd)[NC], StepResult &o) {
     Integrator<NC, NG, WALLS, ACCEL> I;
     I.begin(h_total, half_world, gm, F, om, alpha, w_limit, x0, y0, th0, vx0, vy0, cax, cay, cR, cRd);
-    while (I.attempt(o) == kRkContinue) {}
+    I.run(o);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1188,7 +1198,7 @@ SG_FN void goal_env_step(const SgDev &c, GoalEnv<N> &e, float a0, float a1, floa
                          int &done, int &hit, StepResult &r) {
     Integrator<N, N, true, ACCEL> I;
     goal_env_begin<N, ACCEL>(c, e, a0, a1, I);
-    while (I.attempt(r) == kRkContinue) {}
+    I.run(r);
     goal_env_finish<N>(c, e, r, obs, reward, done, hit);
 }
 
