@@ -15,6 +15,7 @@ their own roofline block.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -39,9 +40,11 @@ def measured_traffic(env_id, batch, kernel_name, steps_per_launch):
     offline with tools/gpu_profile.sh and committed under profiles/; null unless a measurement of THIS kernel on this
     workload exists (the per-step part scales with the steps per launch)."""
     try:
-        for t in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["measurements"]:
-            if t["env_id"] == env_id and t["batch"] == batch and t["kernel"] == kernel_name:
-                return t["hbm_bytes_per_launch"] * steps_per_launch / t["steps_per_launch"]
+        ms = [t for t in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["measurements"]
+              if t["env_id"] == env_id and t["batch"] == batch and t["kernel"] == kernel_name]
+        if ms:  # the measurement taken at these steps per launch, else the nearest one scaled (a launch's fixed part is small)
+            t = min(ms, key=lambda t: abs(math.log(t["steps_per_launch"] / max(1, steps_per_launch))))
+            return t["hbm_bytes_per_launch"] * steps_per_launch / t["steps_per_launch"]
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return None
