@@ -231,9 +231,8 @@ SG_FN f2 pull(f2 c0, f2 c1, f2 c2, f2 c3, f2 p, float (&r2)[NG > 0 ? NG : 1]) {
 
 // dynamic_model.make_step (dynamic_model.py:94-125) in fp32, as a resumable integrator: begin() does what
 // RungeKutta.__init__ + the first event evaluation do, attempt() is one pass of RungeKutta._step_impl's loop body (one
-// accepted or rejected RK step) followed by solve_ivp's event handling.  make_step() below runs them to completion
-// (one launch per step); the rollout kernel calls attempt() once per loop iteration so that lanes whose env needs a
-// second RK step do not hold back the lanes that are done (sg_engine.hip).
+// accepted or rejected RK step) followed by solve_ivp's event handling; run() loops over the attempts of one env-step (one
+// pass per attempt for the whole wave: lanes that are done sit out) and takes the result.
 //   NC circles with radii cR (Goal: the planets; Kepler: planet + border, both centred on the origin),
 //   the first NG of them gravitate; WALLS adds the world_max / world_min events (dynamic_model.py:196-208).
 //   The angular-velocity event (:210-212, limit 6) cannot fire: |omega| = |5 a1| <= 5 for actions in [-1, 1].
@@ -243,7 +242,7 @@ enum : int { kRkContinue = 0, kRkFinished = 1, kRkEvent = 2, kRkEventDeferred = 
 template <int NC, int NG, bool WALLS, bool ACCEL = false>
 struct Integrator {
     // constants of the env-step
-    float t_end, half_world, gm, F, om, alpha, w_limit, x0, y0, nCF, nSF;  // om: omega at t = 0; alpha: d omega / dt; nCF, nSF: accel()
+    float t_end, half_world, gm, F, om, alpha, w_limit, x0, y0, nCF, nSF;  // om: omega at t = 0; alpha: d omega / dt; nCF, nSF: -F (cos, sin) theta0 (thrust_at)
     float cax[NC], cay[NC], cR[NC], cR2[NC];
     f2 cq0, cq1, cq2, cq3;  // centres relative to the start position, (x, y) pairs (named: see pull())
     SG_MFN f2 cq_at(int k) const { return k == 0 ? cq0 : k == 1 ? cq1 : k == 2 ? cq2 : cq3; }
@@ -252,7 +251,7 @@ struct Integrator {
     // running state
     float t, X, Y, vx, vy, h_abs;
     double Xd, Yd;
-    float k0[4], g[NC + 2];
+    float k0[4], g[NC + 2];  // k0: stage 1 of the next attempt (v, a) -- FSAL; g: event functions at the start of the env-step
     bool rejected;
     int n_rk, attempts;
 
