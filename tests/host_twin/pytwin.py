@@ -58,3 +58,12 @@ class Twin:
         c = (C.c_uint32 * 4)(*ctr); o = (C.c_uint32 * 4)()
         self.lib.twin_philox(C.c_uint32(key[0]), C.c_uint32(key[1]), c, o)
         return list(o)
+
+
+def sincos(which, r):
+    """which: 0 sincos_small, 1 sincos_small2 (x of the sine, y of the cosine of the pair (r, -r)), 2 sincos_acc"""
+    lib = C.CDLL(_build.build())
+    r = np.ascontiguousarray(r, np.float32)
+    s, c = np.empty_like(r), np.empty_like(r)
+    lib.twin_sincos(C.c_int(which), C.c_int64(r.size), _p(r, C.c_float), _p(s, C.c_float), _p(c, C.c_float))
+    return s, c

@@ -143,3 +143,15 @@ extern "C" void twin_philox(uint32_t k0, uint32_t k1, const uint32_t *ctr, uint3
     philox4x32_10(k0, k1, ctr[0], ctr[1], ctr[2], ctr[3], o);
     std::memcpy(out, o, sizeof(o));
 }
+
+// the integrator's short sine / cosine (single and two at a time) and the general one, for the accuracy test
+extern "C" void twin_sincos(int which, int64_t n, const float *r, float *s, float *c) {
+    for (int64_t i = 0; i < n; i++) {
+        if (which == 0) sg::sincos_small(r[i], s[i], c[i]);
+        else if (which == 1) {
+            sg::f2 ss, cc;
+            sg::sincos_small2(sg::mk2(r[i], -r[i]), ss, cc);
+            s[i] = ss.x; c[i] = cc.y;
+        } else sg::sincos_acc(r[i], s[i], c[i]);
+    }
+}

@@ -43,6 +43,23 @@ def test_fp32_device_math_matches_reference_golden(fam, golden_steps):
     assert rel.max() <= TOL_REWARD_REL
 
 
+def test_short_sincos_is_exact_to_fp32_rounding_on_its_interval():
+    """sincos_small serves the heading advance inside one env-step with Steering.velocity: |5 a1| * 0.07 <= 0.35 (the action
+    is clipped by translate_action).  Within 0.36 it is as good as fp32 gets; beyond, the error grows smoothly."""
+    from pytwin import sincos
+    r = np.linspace(-0.36, 0.36, 400001).astype(np.float32)
+    for which in (0, 1):
+        s, c = sincos(which, r)
+        assert np.abs(s - np.sin(r.astype(np.float64))).max() <= 3e-8
+        assert np.abs(c - np.cos(r.astype(np.float64))).max() <= 6e-8   # half an ulp of 1
+    r = np.linspace(-0.45, 0.45, 100001).astype(np.float32)
+    s, c = sincos(0, r)
+    assert np.abs(s - np.sin(r.astype(np.float64))).max() <= 3e-7 and np.abs(c - np.cos(r.astype(np.float64))).max() <= 1e-7
+    r = np.linspace(-50.0, 50.0, 400001).astype(np.float32)   # the general one (heading at the start of a step)
+    s, c = sincos(2, r)
+    assert np.abs(s - np.sin(r.astype(np.float64))).max() <= 2e-7 and np.abs(c - np.cos(r.astype(np.float64))).max() <= 2e-7
+
+
 def test_philox_known_answers():
     """Random123 known-answer vectors for philox4x32-10, on the oracle and on the engine's device code."""
     o, t = Oracle("GoalContinuous2P-v0"), Twin("GoalContinuous2P-v0")
