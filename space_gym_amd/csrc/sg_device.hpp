@@ -406,30 +406,38 @@ struct Integrator {
         // rk_step (rk.py:14-71); K_s = (v_s, a_s) as two pairs.  sa_s = sum_l A_sl a_l, i.e. (v_s - V) / h: kept for the
         // error estimate below.
         float r2x[NG > 0 ? NG : 1], r2n[NG > 0 ? NG : 1];
+        // The stage position needs the velocities of the earlier stages, and those the accelerations up to the stage before
+        // last: the accelerations of stages 2 and 3 depend on stage 1 only, those of 4 and 5 on 2 and 3, those of 6 and the
+        // FSAL stage on 4 and 5 -- two interleaved chains of three, written pair by pair so that the scheduler sees them.
         const f2 sa1 = a0 * A21;
         const f2 v1 = fma2(h, sa1, V);
-        const f2 a1 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, V * A21, P), r2x), th1);
+        const f2 g1 = pull<NG>(cq0, cq1, cq2, cq3, fma2(h, V * A21, P), r2x);
+        const f2 g2 = pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A32, v1, V * A31), P), r2x);
+        const f2 a1 = fma2(gm, g1, th1), a2 = fma2(gm, g2, th2);
         const f2 sa2 = fma2(A32, a1, a0 * A31);
         const f2 v2 = fma2(h, sa2, V);
-        const f2 a2 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A32, v1, V * A31), P), r2x), th2);
         const f2 sa3 = fma2(A43, a2, fma2(A42, a1, a0 * A41));
         const f2 v3 = fma2(h, sa3, V);
-        const f2 a3 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A43, v2, fma2(A42, v1, V * A41)), P), r2x), th3);
+        const f2 g3 = pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A43, v2, fma2(A42, v1, V * A41)), P), r2x);
+        const f2 g4 = pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A54, v3, fma2(A53, v2, fma2(A52, v1, V * A51))), P), r2x);
+        const f2 a3 = fma2(gm, g3, th3), a4 = fma2(gm, g4, th4);
         const f2 sa4 = fma2(A54, a3, fma2(A53, a2, fma2(A52, a1, a0 * A51)));
         const f2 v4 = fma2(h, sa4, V);
-        const f2 a4 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A54, v3, fma2(A53, v2, fma2(A52, v1, V * A51))), P), r2x), th4);
         const f2 sa5 = fma2(A65, a4, fma2(A64, a3, fma2(A63, a2, fma2(A62, a1, a0 * A61))));
         const f2 v5 = fma2(h, sa5, V);
-        const f2 a5 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A65, v4, fma2(A64, v3, fma2(A63, v2, fma2(A62, v1, V * A61)))), P), r2x), th5);
-        // v_new - v = h * sum_j B_j a_j; the position increment in Nystrom form, h v + h^2 sum_l beta_l a_l, accumulated in fp64
-        const f2 sa6 = fma2(B6, a5, fma2(B5, a4, fma2(B4, a3, fma2(B3, a2, a0 * B1))));
+        // the position increment in Nystrom form, h v + h^2 sum_l beta_l a_l, accumulated in fp64
         const f2 nys = fma2(BETA5, a4, fma2(BETA4, a3, fma2(BETA3, a2, a0 * BETA1))) * (h * h);
         const double Xdn = Xd + ((double)h * (double)vx + (double)nys.x);
         const double Ydn = Yd + ((double)h * (double)vy + (double)nys.y);
         const float Xn = (float)Xdn, Yn = (float)Ydn;
-        const f2 Pn = mk2(Xn, Yn), v6 = fma2(h, sa6, V);
+        const f2 Pn = mk2(Xn, Yn);
+        const f2 g5 = pull<NG>(cq0, cq1, cq2, cq3, fma2(h, fma2(A65, v4, fma2(A64, v3, fma2(A63, v2, fma2(A62, v1, V * A61)))), P), r2x);
+        const f2 g6 = pull<NG>(cq0, cq1, cq2, cq3, Pn, r2n);
+        const f2 a5 = fma2(gm, g5, th5), a6 = fma2(gm, g6, th5);  // a6: f_new (FSAL)
+        // v_new - v = h * sum_j B_j a_j
+        const f2 sa6 = fma2(B6, a5, fma2(B5, a4, fma2(B4, a3, fma2(B3, a2, a0 * B1))));
+        const f2 v6 = fma2(h, sa6, V);
         const float vxn = v6.x, vyn = v6.y;
-        const f2 a6 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, Pn, r2n), th5);  // f_new (FSAL)
 
         // error norm over six components; theta and omega contribute exactly zero (sum E = 0, d omega/dt = 0).
         // sum_j E_j K_j on differences to stage 1 (sum E = 0); for the position components K_j = v_j and v_j - V = h sa_j:
