@@ -14,8 +14,8 @@ def _p(a, t):
 
 
 class Twin:
-    def __init__(self, env_id, steering_acceleration=False):
-        self.lib = C.CDLL(_build.build())
+    def __init__(self, env_id, steering_acceleration=False, defines=(), tag=""):
+        self.lib = C.CDLL(_build.build(defines=defines, tag=tag))
         self.steering_acceleration = bool(steering_acceleration)
         self.env_id = env_id.encode()
         self.obs_dim = self.lib.twin_obs_dim(self.env_id)

@@ -29,8 +29,12 @@ def test_fp32_device_math_matches_reference_golden(fam, golden_steps):
     d = golden_steps[fam]
     r = Twin(FAMILIES[fam]).step(d["state0"], d["action"], d.get("planets"), d.get("goal"))
     assert np.array_equal(r["done"], d["done"]) and np.array_equal(r["goal_hit"], d["goal_changed"])
-    # the engine runs scipy's RK45 controller in fp32: same number of accepted steps, same terminal event
-    assert np.array_equal(r["n_rk"], d["n_rk_steps"])
+    # the engine runs scipy's RK45 controller in fp32: same number of accepted steps, same terminal event -- except that an
+    # env-step which scipy splits and which ends without an event may be covered by ONE probe step (Integrator::attempt):
+    # the engine then counts one step where scipy has two or more, never the other way round
+    n_rk, ref = r["n_rk"], d["n_rk_steps"]
+    probe_kept = (n_rk == 1) & (ref > 1) & (d["done"] == 0)
+    assert ((n_rk == ref) | probe_kept).all()
     term = d["done"] == 1
     assert np.array_equal(r["event"][term], d["event_index"][term])
     assert np.abs(r["t"][term] - d["t_event"][term]).max() < 1e-6
@@ -58,6 +62,40 @@ def test_short_sincos_is_exact_to_fp32_rounding_on_its_interval():
     r = np.linspace(-50.0, 50.0, 400001).astype(np.float32)   # the general one (heading at the start of a step)
     s, c = sincos(2, r)
     assert np.abs(s - np.sin(r.astype(np.float64))).max() <= 2e-7 and np.abs(c - np.cos(r.astype(np.float64))).max() <= 2e-7
+
+
+@pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "KeplerEllipseHard-v0"])
+def test_probe_step_build_option_stays_within_tolerance(env_id):
+    """-DSG_PROBE_NORM=1e-4f (off by default): an env-step that scipy splits is covered by one RK step when that step's error
+    norm is far below the tolerance and no event can have happened.  Decisions and tolerances as for the default build, on
+    random transitions and on the adversarial terminal cases; only the accepted-step count may be lower."""
+    o = Oracle(env_id, threads=4)
+    t = Twin(env_id, defines=("SG_PROBE_NORM=1e-4f",), tag="_probe")
+    envs, _ = o.vec_reset(20000, seed=7)
+    rng = np.random.default_rng(2)
+    for _ in range(3):
+        o.vec_step(envs, rng.uniform(-1, 1, (len(envs), 2)).astype(np.float32), seed=7)
+    s0 = np.array(envs["state"]).astype(np.float32)
+    a = rng.uniform(-1, 1, (len(envs), 2)).astype(np.float32)
+    Pk = np.array(envs["planets_xy"])[:, :o.n_planets].astype(np.float32) if o.is_goal else None
+    gk = np.array(envs["goal_xy"]).astype(np.float32) if o.is_goal else None
+    kept = 0
+    for k, (S0, A, P, G) in enumerate(((s0, a, Pk, gk), adversarial_event_cases(o, n=30000, seed=3))):
+        ref = o.step(S0.astype(np.float64), A, None if P is None else P.astype(np.float64),
+                     None if G is None else G.astype(np.float64), with_diag=True)
+        tw = t.step(S0, A, P, G)
+        term = ref["done"] == 1
+        assert np.array_equal(tw["done"], ref["done"]) and np.array_equal(tw["event"][term], ref["diag"]["event_index"][term])
+        n_rk, nref = tw["n_rk"], ref["diag"]["n_rk_steps"]
+        probe = (n_rk == 1) & (nref > 1) & ~term
+        if k == 0:  # (the adversarial grazes are not held to scipy's step count by the default build either)
+            assert ((n_rk == nref) | probe).all()
+            kept = int(probe.sum())
+        assert np.abs(tw["state1"][:, [0, 1, 3, 4, 5]] - ref["state1"][:, [0, 1, 3, 4, 5]]).max() <= TOL_STATE
+        assert circ_diff(tw["state1"][:, 2].astype(np.float64), ref["state1"][:, 2]).max() <= TOL_STATE
+        assert np.abs(tw["obs"] - ref["obs"]).max() <= TOL_OBS
+        assert (np.abs(tw["reward"] - ref["reward"]) / np.maximum(1, np.abs(ref["reward"]))).max() <= TOL_REWARD_REL
+    assert kept > 3000  # (about a quarter of the random transitions are split by scipy; the probe step covers 99 % of them)
 
 
 def test_philox_known_answers():
