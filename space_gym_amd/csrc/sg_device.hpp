@@ -170,15 +170,32 @@ constexpr float P71 = (float)(40617522.0 / 29380423.0), P72 = (float)(-110615467
                 P73 = (float)(69997945.0 / 29380423.0);
 constexpr float kRtol = 1e-3f, kAtol = 1e-6f;  // solve_ivp defaults (dynamic_model.py:112-118 passes none)
 constexpr float kSafety = 0.9f, kMinFactor = 0.2f, kMaxFactor = 10.0f;  // rk.py:8-11
-// Probe step (see Integrator::attempt; a build option, OFF by default: -DSG_PROBE_NORM=1e-4f turns it on): when
-// select_initial_step would split the env-step, one step over the whole of it is tried first and kept if its error norm is
-// below kProbeNorm (the tolerance is norm < 1) and no event can have happened.  Measured: 6.5 % faster at
-// 1000 steps per launch, 1.5 % slower at 20, results within 5e-7 of the default build's; the accepted-step count then differs
-// from scipy's, which the default build reproduces.
+// Probe step (see Integrator::attempt).  Every env-step is first tried as ONE Dormand-Prince step over the whole of it, before
+// anything of scipy's step-size machinery is evaluated.  The step is kept if its error norm is below kProbeNorm (scipy's
+// tolerance is norm < 1) and no event can have happened; a step that ends beyond a terminal surface with so small an error is
+// terminal, and only its terminal state -- which feeds the x1000 reward -- is worked out on scipy's own step sequence; everything
+// else follows scipy's sequence from t = 0 (select_initial_step and so on).  79 % of the env-steps are one full step for scipy
+// too (the probe step IS its step); where scipy splits, the kept step ends within 3e-9 of scipy's two-step result (fp64, 221 771
+// such steps of random rollouts: all had an error norm below 1e-3).  -DSG_PROBE_NORM=0.0f switches the probe off (A/B builds).
 #ifndef SG_PROBE_NORM
-#define SG_PROBE_NORM 0.0f
+#define SG_PROBE_NORM 1e-3f
 #endif
 constexpr float kProbeNorm = SG_PROBE_NORM;
+// ... and the step's estimate of its own position error (the 4th- against the 5th-order position, absolute) below kProbePosErr.
+// That is the quantity the Goal reward amplifies x1000: on 360 000 adversarial env-steps (|v| up to 2.5 within 7 cm of a surface)
+// kept steps with an estimate below 3e-8 are within 3.6e-6 (relative) of the reference's reward, those above it up to 1.6e-5;
+// in random rollouts 1e-5 of the env-steps exceed 2e-8 (99.99 % are below 1.3e-8).
+#ifndef SG_PROBE_POS_ERR
+#define SG_PROBE_POS_ERR 2e-8f
+#endif
+constexpr float kProbePosErr = SG_PROBE_POS_ERR;
+// Kepler (no x1000 in its reward: where the reward is steep -- on the reference orbit, engine off -- the estimate is below 1e-9
+// and kept steps are within fp32 rounding of the reference, 2e-6 relative; the estimate grows to 6e-7 only next to the planet,
+// where the reward is flat): bounded for the state's sake (tolerance 1e-5).
+#ifndef SG_PROBE_POS_ERR_KEPLER
+#define SG_PROBE_POS_ERR_KEPLER 1e-6f
+#endif
+constexpr float kProbePosErrKepler = SG_PROBE_POS_ERR_KEPLER;
 constexpr int kMaxRkAttempts = 12;  // bound on accepted+rejected RK steps per env-step (reference mean: 1.19)
 constexpr int kRootIters = 2;      // minimum fp32 safeguarded-Newton iterations before the fp64 Newton polish ...
 constexpr int kRootMaxIters = 28;  // ... and the cap for lanes that have not settled by then (near-tangent grazes)
@@ -192,7 +209,13 @@ struct StepResult {
     int done;        // a terminal event fired (dynamic_model.py:124)
     int event;       // circle index, NC = world_max, NC + 1 = world_min
     int n_rk;        // accepted RK45 steps (diagnostics)
+    int path;        // diagnostics: how the env-step was integrated (kPath*)
+    float probe_err; // diagnostics: squared error norm of the probe step
+    float probe_ep, probe_ev;  // diagnostics: largest absolute error estimate of a position / velocity component
 };
+// kept probe step | probe step beyond a terminal surface (terminal state from scipy's sequence) | scipy's sequence because the
+// probe step's error norm was not small | ... because a graze between the probe step's ends could not be excluded | probe off
+enum : int { kPathProbe = 0, kPathProbeTerminal = 1, kPathScipyErr = 2, kPathScipyClear = 3, kPathScipy = 4 };
 
 // RHS acceleration at displacement p = (X, Y) from the start position and heading advance delta since the step started:
 // thrust -(cos, sin)(theta0 + delta) * F  (dynamic_model.py:168-176) + sum of planet pulls (helpers.py:22-35), as
@@ -261,9 +284,11 @@ struct Integrator {
     float t, X, Y, vx, vy, h_abs;
     double Xd, Yd;
     float k0[4], g[NC + 2];  // k0: stage 1 of the next attempt (v, a) -- FSAL; g: event functions at the start of the env-step
-    bool rejected, probe;  // probe: the first attempt covers the whole env-step although select_initial_step chose less (h_first)
-    float h_first;
-    int n_rk, attempts;
+    bool rejected, probe;  // probe: the next attempt is the probe step (one step over the whole env-step, before select_initial_step)
+    bool probe_crossing;   // the probe step ended beyond a terminal surface with a small error: the env-step is terminal
+    float th0;             // heading at t = 0 (select_initial_step's scale)
+    int n_rk, attempts, path;
+    float probe_err, probe_ep, probe_ev;  // diagnostics
 
     // An accepted RK step over which at least one event function changed sign: everything solve_event() needs besides the
     // env-step constants (set_constants).  The rollout kernel's pilot wave hands such cases to its finisher wave.
@@ -311,20 +336,20 @@ struct Integrator {
     }
 
     SG_MFN void begin(float h_total, float half_world_, float gm_, float F_, float om_, float alpha_, float w_limit_,
-                      float x0_, float y0_, float th0, float vx0, float vy0, const float (&cax_)[NC],
-                      const float (&cay_)[NC], const float (&cR_)[NC], const double (&cRd_)[NC]) {
+                      float x0_, float y0_, float th0_, float vx0, float vy0, const float (&cax_)[NC],
+                      const float (&cay_)[NC], const float (&cR_)[NC], const double (&cRd_)[NC], bool use_probe = true) {
         SG_STAMP(8);
         set_constants(h_total, half_world_, gm_, F_, om_, alpha_, w_limit_, x0_, y0_, cax_, cay_, cR_, cRd_);
         {
             float S0, C0;
-            sincos_acc(th0, S0, C0);
+            sincos_acc(th0_, S0, C0);
             nCF = -(C0 * F); nSF = -(S0 * F);
         }
         t = 0.0f; X = 0.0f; Y = 0.0f; vx = vx0; vy = vy0;
         Xd = 0.0; Yd = 0.0;
-        const f2 T = mk2(nCF, nSF), Tp = mk2(-nSF, nCF), V = mk2(vx, vy);
+        const f2 T = mk2(nCF, nSF);
 
-        // RungeKutta.__init__ (rk.py:85-105): f0, then common.py select_initial_step
+        // RungeKutta.__init__ (rk.py:85-105): f0
         float r2s[NG > 0 ? NG : 1];  // |p - c_j|^2 at the start
         f2 origin = mk2(0.0f, 0.0f);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -334,37 +359,13 @@ struct Integrator {
 #endif
         const f2 a0 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, origin, r2s), T);  // (heading advance 0: the thrust is T itself)
         k0[0] = vx; k0[1] = vy; k0[2] = a0.x; k0[3] = a0.y;
-        {
-            // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega), as the pairs (x, y), (vx, vy)
-            // and the two scalars theta, omega
-            const f2 is_p = mk2(rcp(fmaf(fabsf(x0), kRtol, kAtol)), rcp(fmaf(fabsf(y0), kRtol, kAtol)));
-            const f2 is_v = mk2(rcp(fmaf(fabsf(vx), kRtol, kAtol)), rcp(fmaf(fabsf(vy), kRtol, kAtol)));
-            const float isth = rcp(fmaf(fabsf(th0), kRtol, kAtol)), isom = rcp(fmaf(fabsf(om), kRtol, kAtol));
-            const f2 y_p = mk2(x0, y0) * is_p, y_v = V * is_v;
-            const float y_th = th0 * isth, y_om = om * isom;
-            const f2 n0 = fma2(y_v, y_v, y_p * y_p);
-            const float d0 = fsqrt(fmaf(y_om, y_om, fmaf(y_th, y_th, n0.x + n0.y)) * (1.0f / 6));
-            // f0 = (vx, vy, omega, ax, ay, alpha)
-            const f2 f_p = V * is_p, f_v = a0 * is_v;
-            const float f_th = om * isth, f_om = ACCEL ? alpha * isom : 0.0f;
-            const f2 n1 = fma2(f_v, f_v, f_p * f_p);
-            const float d1 = fsqrt(fmaf(f_om, f_om, fmaf(f_th, f_th, n1.x + n1.y)) * (1.0f / 6));
-            float h0 = (fminf(d0, d1) < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);  // d0 < 1e-5 or d1 < 1e-5 (common.py:96-99)
-            h0 = fminf(h0, t_end);
-            // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)   (Euler probe: theta1 = theta0 + h0 omega, omega1 = omega + h0 alpha)
-            float r2p[NG > 0 ? NG : 1];
-            const f2 a1 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, V * h0, r2p), thrust_at<!ACCEL>(T, Tp, h0 * om));
-            const f2 e_p = (a0 * h0) * is_p, e_v = (a1 - a0) * is_v;
-            const float e_th = ACCEL ? h0 * alpha * isth : 0.0f;
-            const f2 n2 = fma2(e_v, e_v, e_p * e_p);
-            const float d2 = fsqrt(fmaf(e_th, e_th, n2.x + n2.y) * (1.0f / 6)) * rcp(h0);
-            const float dm = fmaxf(d1, d2);
-            const float h1 = (dm <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
-                                            : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
-            h_abs = fminf(fminf(100.0f * h0, h1), t_end);
-            h_first = h_abs;
-            probe = !ACCEL && kProbeNorm > 0.0f && h_abs < t_end;
-        }
+        th0 = th0_;
+        // the probe step comes first; select_initial_step only for the lanes whose probe step is not kept (attempt())
+        // (use_probe = false: scipy's sequence straight away -- the replay of an env-step that is known to be terminal)
+        probe = kProbeNorm > 0.0f && use_probe;
+        probe_crossing = false;
+        path = kPathScipy; probe_err = probe_ep = probe_ev = 0.0f;
+        if (probe) h_abs = t_end; else initial_step();
 
         SG_STAMP(9);
         // event functions at (t0, y0), ivp.py:646.  attempt() only needs the SIGN of a circle event |p - c| - R (which events
@@ -379,11 +380,45 @@ struct Integrator {
         rejected = false; n_rk = 0; attempts = 0;
     }
 
+    // common.py select_initial_step (called from RungeKutta.__init__, rk.py:85-105) at (t0, y0): sets h_abs.  Needs begin().
+    SG_MFN void initial_step() {
+        const f2 T = mk2(nCF, nSF), Tp = mk2(-nSF, nCF), V = mk2(k0[0], k0[1]), a0 = mk2(k0[2], k0[3]);
+        // scale = atol + |y0| rtol over all SIX components (x, y, theta, vx, vy, omega), as the pairs (x, y), (vx, vy)
+        // and the two scalars theta, omega
+        const f2 is_p = mk2(rcp(fmaf(fabsf(x0), kRtol, kAtol)), rcp(fmaf(fabsf(y0), kRtol, kAtol)));
+        const f2 is_v = mk2(rcp(fmaf(fabsf(V.x), kRtol, kAtol)), rcp(fmaf(fabsf(V.y), kRtol, kAtol)));
+        const float isth = rcp(fmaf(fabsf(th0), kRtol, kAtol)), isom = rcp(fmaf(fabsf(om), kRtol, kAtol));
+        const f2 y_p = mk2(x0, y0) * is_p, y_v = V * is_v;
+        const float y_th = th0 * isth, y_om = om * isom;
+        const f2 n0 = fma2(y_v, y_v, y_p * y_p);
+        const float d0 = fsqrt(fmaf(y_om, y_om, fmaf(y_th, y_th, n0.x + n0.y)) * (1.0f / 6));
+        // f0 = (vx, vy, omega, ax, ay, alpha)
+        const f2 f_p = V * is_p, f_v = a0 * is_v;
+        const float f_th = om * isth, f_om = ACCEL ? alpha * isom : 0.0f;
+        const f2 n1 = fma2(f_v, f_v, f_p * f_p);
+        const float d1 = fsqrt(fmaf(f_om, f_om, fmaf(f_th, f_th, n1.x + n1.y)) * (1.0f / 6));
+        float h0 = (fminf(d0, d1) < 1e-5f) ? 1e-6f : 0.01f * d0 * rcp(d1);  // d0 < 1e-5 or d1 < 1e-5 (common.py:96-99)
+        h0 = fminf(h0, t_end);
+        // y1 = y0 + h0 f0 ; f1 = fun(t0 + h0, y1)   (Euler probe: theta1 = theta0 + h0 omega, omega1 = omega + h0 alpha)
+        float r2p[NG > 0 ? NG : 1];
+        const f2 a1 = fma2(gm, pull<NG>(cq0, cq1, cq2, cq3, V * h0, r2p), thrust_at<!ACCEL>(T, Tp, h0 * om));
+        const f2 e_p = (a0 * h0) * is_p, e_v = (a1 - a0) * is_v;
+        const float e_th = ACCEL ? h0 * alpha * isth : 0.0f;
+        const f2 n2 = fma2(e_v, e_v, e_p * e_p);
+        const float d2 = fsqrt(fmaf(e_th, e_th, n2.x + n2.y) * (1.0f / 6)) * rcp(h0);
+        const float dm = fmaxf(d1, d2);
+        const float h1 = (dm <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
+                                        : fexp2(0.2f * flog2(0.01f * rcp(dm)));  // (0.01/dm)^(1/5)
+        h_abs = fminf(fminf(100.0f * h0, h1), t_end);
+    }
+
     // One RK attempt.  Returns kRkContinue, kRkFinished (the caller then takes the result with finish(): run() below), or
     // fills `o` and returns kRkEvent / kRkEventDeferred.
-    // `sink(ev)`: called for an accepted step with an event before it is solved; if it returns true the case has been taken
-    // over (o.done = 1, return value kRkEventDeferred), else it is solved here.
-    struct NoSink { SG_MFN bool operator()(const EventCase &) const { return false; } };
+    // `sink()`: asked when the env-step is known to be terminal -- the probe step ended beyond a terminal surface, or an
+    // accepted step of scipy's sequence has an event -- before anything is solved; if it returns true the caller takes the
+    // terminal state from elsewhere (o.done = 1, return value kRkEventDeferred: the wave-pair rollout kernels replay such
+    // env-steps in batches), else it is worked out here.
+    struct NoSink { SG_MFN bool operator()() const { return false; } };
     template <typename SINK = NoSink>
     SG_MFN int attempt(StepResult &o, SINK &&sink = NoSink()) {
         // (t < t_end holds on entry: begin() starts at t = 0 and the exits below leave the loop once t_end is reached or the
@@ -394,7 +429,7 @@ struct Integrator {
         // RungeKutta._step_impl (rk.py:111-176)
         h_abs = fmaxf(h_abs, 1e-9f);
         float t_new = t + h_abs;
-        if (t_new - t_end > 0.0f || probing) t_new = t_end;
+        if (t_new - t_end > 0.0f) t_new = t_end;
         const float h = t_new - t;
         h_abs = h;
         const f2 V = mk2(vx, vy), P = mk2(X, Y), a0 = mk2(k0[2], k0[3]);  // K_1 = (V, a0): velocity and acceleration at t (FSAL)
@@ -456,7 +491,7 @@ struct Integrator {
         // error norm over six components; theta and omega contribute exactly zero (sum E = 0, d omega/dt = 0).
         // sum_j E_j K_j on differences to stage 1 (sum E = 0); for the position components K_j = v_j and v_j - V = h sa_j:
         // the stage sums themselves, without the cancellation of a subtraction.
-        float err2;
+        float err2, abs_ep, abs_ev;
         {
             const f2 e_p = fma2(E7, sa6, fma2(E6, sa5, fma2(E5, sa4, fma2(E4, sa3, sa2 * E3)))) * h;
             const f2 e_v = fma2(E7, a6 - a0, fma2(E6, a5 - a0, fma2(E5, a4 - a0, fma2(E4, a3 - a0, (a2 - a0) * E3))));
@@ -466,6 +501,7 @@ struct Integrator {
             const f2 q_p = (e_p * h) * mk2(rcp(sc_p.x), rcp(sc_p.y)), q_v = (e_v * h) * mk2(rcp(sc_v.x), rcp(sc_v.y));
             const f2 n = fma2(q_v, q_v, q_p * q_p);
             err2 = n.x + n.y;
+            abs_ep = fmaxf(fabsf(e_p.x), fabsf(e_p.y)) * h; abs_ev = fmaxf(fabsf(e_v.x), fabsf(e_v.y)) * h;
         }
         // err = sqrt(err2 / 6) is only compared with 1 and raised to -1/5 (rk.py:155-168): both from its square
         const float err = err2 * (1.0f / 6);
@@ -490,20 +526,41 @@ struct Integrator {
 #pragma unroll
             for (int k = 0; k < NC + (WALLS ? 2 : 0); k++) { gg[k] = g[k] * gn[k]; ggmin = fminf(ggmin, gg[k]); }
         };
-        constexpr bool kProbeOn = kProbeNorm > 0.0f;
-        if (kProbeOn) end_events();
+        end_events();
+        // angular-velocity event max_abs_vel_angle - |omega| (dynamic_model.py:210-212): only live with Steering.acceleration
+        // (|5 a1| <= 5 otherwise); omega is linear in t, so its root is closed-form
+        float s_w = 2.0f;
+        bool w_event = false;
+        if constexpr (ACCEL) {
+            const float w0 = fmaf(alpha, t, om), w1 = fmaf(alpha, t_new, om);
+            const float gw0 = w_limit - fabsf(w0), gw1 = w_limit - fabsf(w1);
+            if ((gw0 <= 0.0f && gw1 >= 0.0f) || (gw0 >= 0.0f && gw1 <= 0.0f)) {
+                // crossing of +-limit between w0 and w1: the limit with the sign of whichever end is outside / larger
+                const float lim = (fabsf(w1) >= fabsf(w0) ? w1 : w0) >= 0.0f ? w_limit : -w_limit;
+                const float dw = w1 - w0;
+                s_w = (dw != 0.0f) ? fminf(fmaxf((lim - w0) * rcp(dw), 0.0f), 1.0f) : 0.0f;
+                w_event = true;
+            }
+        }
 
-        // Probe step.  select_initial_step splits 23 % of the env-steps (a state component near zero makes its scale, and with
-        // it the first step, small) although one DP5 step over the whole env-step is accurate far beyond the tolerance there:
-        // in fp64, 221 771 such steps of random rollouts all had an error norm below 1e-3 and ended within 3e-9 of scipy's
-        // two-step result.  So the first attempt of such a lane covers the whole step and is kept if its error norm is below
-        // kProbeNorm and no event function changes sign over it; otherwise it is discarded and the lane follows scipy's own
-        // sequence from t = 0 (this attempt was then one too many).  Events, rejections and everything a terminal state feeds
-        // -- the reward multiplies positions by up to 1000 -- are therefore always scipy's; a kept probe step shows as one
-        // accepted RK step where scipy has two.
+        // Probe step: the first attempt of every env-step covers the whole of it (h = t_end), before select_initial_step has
+        // been evaluated at all.
+        //   kept      error norm below kProbeNorm and position error estimate below kProbePosErr, no event function changes sign, and no graze between the two ends possible
+        //             (below): the env-step is this one step.  For 79 % of the env-steps that IS scipy's sequence; where scipy
+        //             splits the step (a state component near zero makes its scale, and so the first step, small) its
+        //             two-step result is within 3e-9 of this one.
+        //   terminal  error norm below kProbeNorm and the step ends beyond a terminal surface: scipy's sequence ends at or
+        //             beyond it too, so the env-step is terminal.  The terminal state -- the reward multiplies it by up to 1000
+        //             -- has to be the root on scipy's own dense output: `sink` may take the env-step over (the wave-pair
+        //             kernels replay it later, many at a time); otherwise scipy's sequence is run here from t = 0.
+        //   else      scipy's sequence from t = 0: select_initial_step, then attempts until t_end.  If it starts with the
+        //             whole env-step, this attempt was its first one and goes on into the accept / reject logic below.
         if (probing) {
-            bool keep = err <= kProbeNorm * kProbeNorm && ggmin > 0.0f;
-            if (keep) {
+            probe_err = err; probe_ep = abs_ep; probe_ev = abs_ev;
+            // (WALLS: the Goal family)
+            const bool small = err <= kProbeNorm * kProbeNorm && abs_ep <= (WALLS ? kProbePosErr : kProbePosErrKepler);
+            const bool crossing = ggmin <= 0.0f || w_event;
+            if (small && !crossing) {
                 // scipy looks at the event functions at the end of each of ITS steps, so it can see a graze that dips below a
                 // surface and comes out again within the env-step; the probe step only has the two ends.  It is kept only
                 // where no such dip is possible: a path of length L <= h |v| whose ends are both outside a circle of radius R
@@ -514,13 +571,26 @@ struct Integrator {
                 float gnear = 3.0e38f;
 #pragma unroll
                 for (int k = 0; k < NC; k++) gnear = fminf(gnear, fminf(fabsf(g[k]), fabsf(gn[k])));
-                keep = gnear > clear;
+                bool keep = gnear > clear;
                 if (WALLS) keep = keep && fminf(fminf(g[NC], gn[NC]), fminf(g[NC + 1], gn[NC + 1])) > 1e-3f;
+                if (keep) {
+                    n_rk = 1; path = kPathProbe;
+                    t = t_new; X = Xn; Y = Yn; Xd = Xdn; Yd = Ydn; vx = vxn; vy = vyn;
+                    return kRkFinished;
+                }
+                path = kPathScipyClear;
+            } else if (small) {
+                probe_crossing = true; path = kPathProbeTerminal;
+                if (sink()) {
+                    o.dXd = 0.0; o.dYd = 0.0; o.dX = 0.0f; o.dY = 0.0f; o.vx = 0.0f; o.vy = 0.0f; o.t = t_end; o.dth = 0.0f; o.om = om;
+                    o.done = 1; o.event = -1; o.n_rk = 0; o.path = path;
+                    return kRkEventDeferred;
+                }
+            } else {
+                path = kPathScipyErr;
             }
-            if (!keep) {
-                h_abs = h_first;
-                return kRkContinue;
-            }
+            initial_step();
+            if (h_abs < t_end) return kRkContinue;  // scipy starts with a shorter step: this attempt was one too many
         }
 
         // safety * err_norm^(-1/5), once for both outcomes (a wave usually has lanes of either kind); err = 0 gives +inf
@@ -538,30 +608,20 @@ struct Integrator {
         n_rk++;
 
         // events over this accepted step
-        if (!kProbeOn) end_events();
         unsigned mask = 0;
         if (ggmin <= 0.0f) {
 #pragma unroll
             for (int k = 0; k < NC + (WALLS ? 2 : 0); k++)
                 if (gg[k] <= 0.0f) mask |= 1u << k;
         }
-
-        // angular-velocity event max_abs_vel_angle - |omega| (dynamic_model.py:210-212): only live with Steering.acceleration
-        // (|5 a1| <= 5 otherwise); omega is linear in t, so its root is closed-form
-        float s_w = 2.0f;
-        if constexpr (ACCEL) {
-            const float w0 = fmaf(alpha, t, om), w1 = fmaf(alpha, t_new, om);
-            const float gw0 = w_limit - fabsf(w0), gw1 = w_limit - fabsf(w1);
-            if ((gw0 <= 0.0f && gw1 >= 0.0f) || (gw0 >= 0.0f && gw1 <= 0.0f)) {
-                // crossing of +-limit between w0 and w1: the limit with the sign of whichever end is outside / larger
-                const float lim = (fabsf(w1) >= fabsf(w0) ? w1 : w0) >= 0.0f ? w_limit : -w_limit;
-                const float dw = w1 - w0;
-                s_w = (dw != 0.0f) ? fminf(fmaxf((lim - w0) * rcp(dw), 0.0f), 1.0f) : 0.0f;
-                mask |= 1u << (NC + 2);
-            }
-        }
+        if (w_event) mask |= 1u << (NC + 2);
 
         if (mask) {
+            if (sink()) {
+                o.dXd = 0.0; o.dYd = 0.0; o.dX = 0.0f; o.dY = 0.0f; o.vx = 0.0f; o.vy = 0.0f; o.t = t; o.dth = 0.0f; o.om = om;
+                o.done = 1; o.event = -1; o.n_rk = n_rk; o.path = path;
+                return kRkEventDeferred;
+            }
             EventCase ev;
             ev.h = h; ev.t = t; ev.X = X; ev.Y = Y; ev.vx = vx; ev.vy = vy; ev.Xn = Xn; ev.Yn = Yn; ev.Xd = Xd; ev.Yd = Yd;
 #pragma unroll
@@ -572,12 +632,8 @@ struct Integrator {
                 ev.k4[i + 2] = i ? a4.y : a4.x; ev.k5[i + 2] = i ? a5.y : a5.x; ev.k6[i + 2] = i ? a6.y : a6.x;
             }
             ev.mask = mask; ev.s_w = s_w; ev.n_rk = n_rk;
-            if (sink(ev)) {
-                o.dXd = 0.0; o.dYd = 0.0; o.dX = 0.0f; o.dY = 0.0f; o.vx = 0.0f; o.vy = 0.0f; o.t = t; o.dth = 0.0f; o.om = om;
-                o.done = 1; o.event = -1; o.n_rk = n_rk;
-                return kRkEventDeferred;
-            }
             solve_event(ev, o);
+            o.path = path; o.probe_err = probe_err; o.probe_ep = probe_ep; o.probe_ev = probe_ev;
             return kRkEvent;
         }
         // (g keeps its values from the start of the env-step: a lane that goes on has seen no sign change and no zero, so every
@@ -592,10 +648,17 @@ struct Integrator {
     // All attempts of one env-step.  The result of a lane that reaches the end of the step is read out of the integrator once,
     // after the loop, not in whichever pass of the loop the lane happens to finish.
     template <typename SINK = NoSink>
-    SG_MFN void run(StepResult &o, SINK &&sink = NoSink()) {
+    SG_MFN int run(StepResult &o, SINK &&sink = NoSink()) {
         int status;
         while ((status = attempt(o, sink)) == kRkContinue) {}
-        if (status == kRkFinished) finish(o);
+        if (status == kRkFinished) {
+            finish(o);
+            // (a probe step that ended beyond a terminal surface makes the env-step terminal -- the kernels that hand such steps
+            //  over have restarted the env by the time the terminal state is worked out.  Should scipy's sequence end a hair on
+            //  the other side of the surface, its end state is the terminal state: no root to look for.)
+            if (probe_crossing) o.done = 1;
+        }
+        return status;
     }
 
     // solve_ivp's event handling for an accepted step with sign changes (ivp.py:673-694): the earliest root over the
@@ -744,16 +807,16 @@ struct Integrator {
     SG_MFN void finish(StepResult &o) const {
         o.dXd = Xd; o.dYd = Yd; o.dX = X; o.dY = Y; o.vx = vx; o.vy = vy; o.t = t;
         o.dth = phase(t); o.om = ACCEL ? fmaf(alpha, t, om) : om;
-        o.done = 0; o.event = -1; o.n_rk = n_rk;
+        o.done = 0; o.event = -1; o.n_rk = n_rk; o.path = path; o.probe_err = probe_err; o.probe_ep = probe_ep; o.probe_ev = probe_ev;
     }
 };
 
 template <int NC, int NG, bool WALLS, bool ACCEL = false>
 SG_FN void make_step(float h_total, float half_world, float gm, float F, float om, float alpha, float w_limit, float x0,
                      float y0, float th0, float vx0, float vy0, const float (&cax)[NC], const float (&cay)[NC],
-                     const float (&cR)[NC], const double (&cRd)[NC], StepResult &o) {
+                     const float (&cR)[NC], const double (&cRd)[NC], StepResult &o, bool use_probe = true) {
     Integrator<NC, NG, WALLS, ACCEL> I;
-    I.begin(h_total, half_world, gm, F, om, alpha, w_limit, x0, y0, th0, vx0, vy0, cax, cay, cR, cRd);
+    I.begin(h_total, half_world, gm, F, om, alpha, w_limit, x0, y0, th0, vx0, vy0, cax, cay, cR, cRd, use_probe);
     I.run(o);
 }
 
@@ -1204,7 +1267,8 @@ SG_FN void kepler_observe(const SgDev &c, const KeplerEnv &e, float (&obs)[10]) 
 // Goal: integrate -> observation (old goal) -> reward; the caller resamples the goal on a hit (goal.py:154-157).
 // Split into begin / finish around the resumable integrator so that the rollout kernel can interleave envs.
 template <int N, bool ACCEL = false>
-SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true, ACCEL> &I) {
+SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true, ACCEL> &I,
+                          bool use_probe = true) {
     float engine, F, om, om0, alpha;
     translate_action(a0, a1, c.max_engine_force, engine, F, om);
     steering<ACCEL>(c, a1, om, e.om, om0, alpha);
@@ -1212,7 +1276,7 @@ SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a
     double cRd[N];
 #pragma unroll
     for (int j = 0; j < N; j++) { cR[j] = c.planet_r; cRd[j] = c.planet_r_d; }
-    I.begin(c.h, c.half_world, c.gm, F, om0, alpha, c.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd);
+    I.begin(c.h, c.half_world, c.gm, F, om0, alpha, c.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd, use_probe);
 }
 
 // The same from a by-value copy of the few parameters it needs: a K-step loop keeps them in registers instead of re-reading
@@ -1228,7 +1292,8 @@ SG_FN StepConsts step_consts(const SgDev &c) {
     return k;
 }
 template <int N, bool ACCEL = false>
-SG_FN void goal_env_begin(const StepConsts &k, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true, ACCEL> &I) {
+SG_FN void goal_env_begin(const StepConsts &k, const GoalEnv<N> &e, float a0, float a1, Integrator<N, N, true, ACCEL> &I,
+                          bool use_probe = true) {
     float engine, F, om, om0, alpha;
     translate_action(a0, a1, k.max_engine_force, engine, F, om);
     if (ACCEL) { om0 = e.om; alpha = (a1 * k.max_thruster_force) * k.inv_moi; }  // steering<ACCEL>
@@ -1237,7 +1302,7 @@ SG_FN void goal_env_begin(const StepConsts &k, const GoalEnv<N> &e, float a0, fl
     double cRd[N];
 #pragma unroll
     for (int j = 0; j < N; j++) { cR[j] = k.planet_r; cRd[j] = k.planet_r_d; }
-    I.begin(k.h, k.half_world, k.gm, F, om0, alpha, k.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd);
+    I.begin(k.h, k.half_world, k.gm, F, om0, alpha, k.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd, use_probe);
 }
 
 template <int N>
@@ -1288,7 +1353,7 @@ SG_FN Orbit fixed_orbit(const SgDev &c) {
 
 template <bool ACCEL = false>
 SG_FN void kepler_env_step(const SgDev &c, const Orbit &ob, KeplerEnv &e, float a0, float a1, float (&obs)[10],
-                           float &reward, int &done, StepResult &r) {
+                           float &reward, int &done, StepResult &r, bool use_probe = true) {
     float engine, F, om, om0, alpha;
     translate_action(a0, a1, c.max_engine_force, engine, F, om);
     steering<ACCEL>(c, a1, om, e.om, om0, alpha);
@@ -1297,7 +1362,7 @@ SG_FN void kepler_env_step(const SgDev &c, const Orbit &ob, KeplerEnv &e, float 
     const float cax[2] = {0.0f, 0.0f}, cay[2] = {0.0f, 0.0f}, cR[2] = {c.planet_r, c.border_r};
     const double cRd[2] = {c.planet_r_d, (double)c.border_r};
     make_step<2, 1, false, ACCEL>(c.h, c.half_world, c.gm, F, om0, alpha, c.omega_limit, e.x, e.y, e.th, e.vx, e.vy, cax, cay,
-                                  cR, cRd, r);
+                                  cR, cRd, r, use_probe);
     reward = kepler_reward(c, ob, e.x, e.y, r.dXd, r.dYd, r.vx, r.vy, engine, a1);
     e.x = (float)((double)e.x + r.dXd); e.y = (float)((double)e.y + r.dYd); e.vx = r.vx; e.vy = r.vy; e.om = r.om;
     e.th = wrap_two_pi(e.th + r.dth);

@@ -24,7 +24,7 @@ class Twin:
         self.discrete = "Discrete" in env_id
         self.n_planets = (self.obs_dim - 9) // 2 if self.is_goal else 0
 
-    def step(self, state, action, planets=None, goal=None):
+    def step(self, state, action, planets=None, goal=None, diag=False):
         state = np.ascontiguousarray(state, np.float32); m = len(state)
         action = np.ascontiguousarray(action, np.int32 if self.discrete else np.float32)
         planets = np.ascontiguousarray(planets, np.float32) if planets is not None else None
@@ -34,9 +34,13 @@ class Twin:
                    t=np.empty(m, np.float32), n_rk=np.empty(m, np.int32), event=np.empty(m, np.int32))
         f, u8, i32 = C.c_float, C.c_uint8, C.c_int32
         self.lib.twin_set_steering_acceleration(int(self.steering_acceleration))
+        if diag:  # how each env-step was integrated (0 probe step kept, 1 probe step terminal, 2 / 3 scipy's sequence, 4 probe off)
+            out["path"], out["probe_err"], out["probe_abs"] = np.empty(m, np.int32), np.empty(m, np.float32), np.empty((m, 2), np.float32)
+            self.lib.twin_set_diag(_p(out["path"], i32), _p(out["probe_err"], f), _p(out["probe_abs"], f))
         rc = self.lib.twin_step(self.env_id, C.c_int64(m), _p(state, f), _p(planets, f), _p(goal, f), action.ctypes.data_as(C.c_void_p),
                                 _p(out["state1"], f), _p(out["obs"], f), _p(out["reward"], f), _p(out["done"], u8),
                                 _p(out["goal_hit"], u8), _p(out["t"], f), _p(out["n_rk"], i32), _p(out["event"], i32))
+        self.lib.twin_set_diag(None, None, None)
         assert rc == 0
         return out
 

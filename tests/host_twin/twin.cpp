@@ -12,6 +12,11 @@ using namespace sg;
 
 // Steering.acceleration for the next twin_step calls (the reference's ship_steering=0; no registered id uses it)
 static int g_steering_acceleration = 0;
+// optional diagnostics of the next twin_step calls: how each env-step was integrated (sg::kPath*) and the probe step's
+// squared error norm
+static int32_t *g_path = nullptr;
+static float *g_probe_err = nullptr, *g_probe_abs = nullptr;
+extern "C" void twin_set_diag(int32_t *path, float *probe_err, float *probe_abs) { g_path = path; g_probe_err = probe_err; g_probe_abs = probe_abs; }
 extern "C" void twin_set_steering_acceleration(int on) { g_steering_acceleration = on ? 1 : 0; }
 
 template <int N, bool ACCEL>
@@ -36,6 +41,9 @@ static void goal_steps(const SgDev &c, int64_t m, const float *state, const floa
         std::memcpy(obs + D * i, o, sizeof(o));
         reward[i] = r; done[i] = (uint8_t)dn; hit[i] = (uint8_t)ht;
         t_adv[i] = sr.t; n_rk[i] = sr.n_rk; event[i] = sr.event;
+        if (g_path) g_path[i] = sr.path;
+        if (g_probe_err) g_probe_err[i] = sr.probe_err;
+        if (g_probe_abs) { g_probe_abs[2 * i] = sr.probe_ep; g_probe_abs[2 * i + 1] = sr.probe_ev; }
     }
 }
 
@@ -87,6 +95,9 @@ extern "C" int twin_step(const char *env_id, int64_t m, const float *state, cons
         std::memcpy(obs + 10 * i, o, sizeof(o));
         reward[i] = r; done[i] = (uint8_t)dn; hit[i] = 0;
         t_adv[i] = sr.t; n_rk[i] = sr.n_rk; event[i] = sr.event;
+        if (g_path) g_path[i] = sr.path;
+        if (g_probe_err) g_probe_err[i] = sr.probe_err;
+        if (g_probe_abs) { g_probe_abs[2 * i] = sr.probe_ep; g_probe_abs[2 * i + 1] = sr.probe_ev; }
     }
     return 0;
 }
