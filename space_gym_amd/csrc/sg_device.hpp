@@ -847,8 +847,9 @@ SG_FN double dist_drop(double lx, double ly, double cx, double cy, double &cur2)
     return (l2 - cur2) * inv;
 }
 
-template <int N>
-SG_FN float goal_reward(const SgDev &c, float x0, float y0, double dX, double dY, const float (&px)[N],
+// (CFG: the parameter block, or a copy of the fields used here that a K-step loop keeps in registers: GoalStepConsts)
+template <int N, typename CFG>
+SG_FN float goal_reward(const CFG &c, float x0, float y0, double dX, double dY, const float (&px)[N],
                         const float (&py)[N], float gx, float gy, int &hit) {
     const double lx = x0, ly = y0, cx = lx + dX, cy = ly + dY;
     double gcur2;
@@ -1244,8 +1245,8 @@ SG_FN void load_action(bool discrete, const void *actions, int64_t idx, float &a
     }
 }
 
-template <int N>
-SG_FN void goal_observe(const SgDev &c, const GoalEnv<N> &e, float (&obs)[7 + 2 * N + 2]) {
+template <int N, typename CFG>
+SG_FN void goal_observe(const CFG &c, const GoalEnv<N> &e, float (&obs)[7 + 2 * N + 2]) {
     float s, co;
     sincos_acc(e.th, s, co);
     obs[0] = e.x; obs[1] = e.y; obs[2] = co; obs[3] = s; obs[4] = e.vx; obs[5] = e.vy; obs[6] = e.om;
@@ -1277,6 +1278,19 @@ SG_FN void goal_env_begin(const SgDev &c, const GoalEnv<N> &e, float a0, float a
 #pragma unroll
     for (int j = 0; j < N; j++) { cR[j] = c.planet_r; cRd[j] = c.planet_r_d; }
     I.begin(c.h, c.half_world, c.gm, F, om0, alpha, c.omega_limit, e.x, e.y, e.th, e.vx, e.vy, e.px, e.py, cR, cRd, use_probe);
+}
+
+// What the reward and the observation of a Goal env-step read of the parameter block (goal_reward, goal_observe), by value: a
+// K-step loop keeps them in registers instead of re-reading the parameter block -- scalar loads with their latency -- every step.
+struct GoalStepConsts {
+    double goal_r2, danger_r2, survival, goal_scale, safety_scale, sparse;
+    float planet_r, two_over_world;
+};
+SG_FN GoalStepConsts goal_step_consts(const SgDev &c) {
+    GoalStepConsts k;
+    k.goal_r2 = c.goal_r2; k.danger_r2 = c.danger_r2; k.survival = c.survival; k.goal_scale = c.goal_scale;
+    k.safety_scale = c.safety_scale; k.sparse = c.sparse; k.planet_r = c.planet_r; k.two_over_world = c.two_over_world;
+    return k;
 }
 
 // The same from a by-value copy of the few parameters it needs: a K-step loop keeps them in registers instead of re-reading

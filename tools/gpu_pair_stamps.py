@@ -14,16 +14,17 @@ import space_gym_amd as sg  # noqa: E402
 from space_gym_amd import _native  # noqa: E402
 
 SLOTS, WAVES = 16, 4096
-PILOT = {0: "top of step (action, loop)", 1: "begin: select_initial_step, g(t0)", 2: "RK attempts + event roots",
-         3: "state update", 4: "wait for a ring slot", 5: "ring record + publish", 8: "TimeLimit + restart"}
-FIN = {0: "loop", 1: "wait for the pilot", 3: "read record, event pass, release slot", 4: "reward + update + observe",
-       5: "owner stores", 6: "refill passes", 7: "restart: pop + cold stores + obs", 2: "goal resamples"}
+PILOT = {0: "top of step (action, waits, loop)", 1: "begin: constants, f(t0), g(t0)", 2: "probe step (+ scipy's sequence)",
+         3: "replay records + state update", 5: "ring record + publish", 8: "TimeLimit + restart"}
+FIN = {0: "loop", 1: "wait for the pilot", 3: "read record, release slot", 4: "reward + update",
+       6: "terminal obs (TOBS) + refill passes", 12: "restart: next episode out of the queue", 13: "observation", 5: "output stores",
+       2: "goal resamples", 9: "replay passes"}
 
 
 def main():
     lib = _native.load()
     lib.sg_debug_read_stamps.argtypes = [C.c_void_p, C.c_int64]
-    B, K = 65536, 500
+    B, K = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 500
     env = sg.make_vec("GoalContinuous3P-v0", B, seed=0)
     dev = torch.device("cuda", 0)
     acts = torch.rand((K, B, 2), device=dev) * 2 - 1
@@ -46,6 +47,7 @@ def main():
     for k, name in FIN.items():
         print("  %-40s %8.0f" % (name, fin[:, k].mean()))
     print("  %-40s %8.0f" % ("total", sum(fin[:, k].mean() for k in FIN)))
+    print("  queue refills per step %.4f, episodes generated per step %.3f" % (fin[:, 10].mean(), fin[:, 11].mean()))
 
 
 if __name__ == "__main__":
