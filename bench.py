@@ -132,7 +132,8 @@ def main():
                          "anything is measured (a 100-step warm-up alone is 0.3 ms)")
     ap.add_argument("--chunk", type=int, default=2000, help="max steps per sg_rollout_device call / rollout buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also time a per-step RCCL gather of (obs,reward,done) to rank 0")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the leg that also gathers every step's (obs, reward, done, "
+                    "truncated) to rank 0 (the single-process VectorEnv view: the only exchange the path has)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the NumPy host-buffer path sample (sg_step, PCIe-inclusive)")
     args = ap.parse_args()
@@ -279,39 +280,68 @@ def main():
         env.set_profiling(False)
     env.set_unfused_rollout(False)
 
+    # ---- N > 1: the same steps with the only exchange the path has -- every rank's (obs, reward, done, truncated) of each step
+    # received into rank 0's [N * B, ...] arrays, one batch of point-to-point transfers per step (space_gym_amd/sharded.py)
     gather_ms = None
-    if args.gather and world > 1:
-        packed = torch.empty((B, D + 2), device=dev, dtype=torch.float32)
-        bufs = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+    if world > 1 and not args.no_gather:
+        Kg = min(K, 50)
+        xdev = torch.device("cpu") if rehearse else dev  # (gloo moves host tensors; RCCL device tensors)
+        root = None
+        if rank == 0:
+            root = [torch.empty((world * B, D), dtype=torch.float32, device=xdev), torch.empty(world * B, dtype=torch.float32, device=xdev),
+                    torch.empty(world * B, dtype=torch.uint8, device=xdev), torch.empty(world * B, dtype=torch.uint8, device=xdev)]
+
+        def step_and_gather(j):
+            env.rollout_torch(act_seq[j:j + 1], obs[j:j + 1], rew[j:j + 1], done[j:j + 1], trunc[j:j + 1])
+            mine = [x[j].to(xdev) for x in (obs, rew, done, trunc)]
+            if rank == 0:
+                for f, x in zip(root, mine):
+                    f[:B].copy_(x)
+                ops = [dist.P2POp(dist.irecv, f[r * B:(r + 1) * B], r) for r in range(1, world) for f in root]
+            else:
+                ops = [dist.P2POp(dist.isend, x, 0) for x in mine]
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+
+        step_and_gather(0)
         sync_all()
         t2 = time.perf_counter()
-        for t in range(K):
-            j = t % chunk
-            env.rollout_torch(act_seq[j:j + 1], obs[j:j + 1], rew[j:j + 1], done[j:j + 1], trunc[j:j + 1])
-            packed[:, :D] = obs[j]; packed[:, D] = rew[j]; packed[:, D + 1] = done[j].float()
-            dist.gather(packed, bufs, dst=0)
+        for t in range(Kg):
+            step_and_gather(t % chunk)
         sync_all()
-        gather_ms = (time.perf_counter() - t2) * 1e3 / K
+        gather_ms = (time.perf_counter() - t2) * 1e3 / Kg
 
-    host_us = None
-    if world == 1 and not args.no_host_path:  # NumPy in / out through sg_step: H2D + kernel + D2H per step (PCIe-inclusive)
+    host_us = host_async_us = None
+    if world == 1 and not args.no_host_path:  # NumPy in / out: H2D + kernel + D2H per step (PCIe-inclusive)
         a_host = act_seq[0].cpu().numpy()
         for _ in range(3):
             env.step(a_host)
+        n_host, t_async = 20, 0.0
         th = time.perf_counter()
-        n_host = 20
         for _ in range(n_host):
-            env.step(a_host)
+            ta = time.perf_counter()
+            env.step_async(a_host)  # everything enqueued: the host is free from here ...
+            t_async += time.perf_counter() - ta
+            env.step_wait()         # ... to here
         host_us = (time.perf_counter() - th) * 1e6 / n_host
+        host_async_us = t_async * 1e6 / n_host
 
     red_dev = torch.device("cpu") if rehearse else dev
-    stats = torch.tensor([dt, dt_unfused, dt_events or 0.0], device=red_dev, dtype=torch.float64)
+    stats = torch.tensor([dt, dt_unfused, dt_events or 0.0, gather_ms or 0.0], device=red_dev, dtype=torch.float64)
     k_last = K - (K - 1) // chunk * chunk  # steps in the last chunk, whose outputs are still in the buffers
     n_done = (done[:k_last].sum(dtype=torch.float64) * (K / k_last)).reshape(1).to(red_dev)
+    ranks_info = None
     if world > 1:
+        # what every rank saw: its clock for the timed region, its device -- so that the line shows N ranks on N devices
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index),
+                "ms_per_step": dt * 1e3 / K, "ms_per_step_median": sorted(repeats)[len(repeats) // 2] * 1e3 / K,
+                "kernel_avg_us": (kern_ms * 1e3 / launches) if launches else None}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(n_done, op=dist.ReduceOp.SUM)
     dt_max, dt_unfused, dt_events = float(stats[0]), float(stats[1]), (float(stats[2]) or None)
+    gather_ms = float(stats[3]) or None
 
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(args.env)
@@ -355,12 +385,19 @@ def main():
                 "traffic": measured_traffic(args.env, B, step_kernel_name, 1), "kernel": step_kernel_name,
                 "kernel_avg_us": u_avg, "kernel_min_us": u_min * 1e3, "kernel_max_us": u_max * 1e3, "launches": u_launches}
         if host_us is not None:
-            out["host_numpy_path"] = {"us_per_step": host_us, "value": B / (host_us * 1e-6), "unit": "env-steps/s",
-                                      "what": "sg_step with NumPy arrays in page-locked memory, no copies on the host side and no "
-                                              "terminal-observation array: H2D of the actions, the step kernel, D2H of obs / reward / done / "
-                                              "truncated per step (PCIe-inclusive; never `value`)"}
+            out["host_numpy_path"] = {"us_per_step": host_us, "us_in_step_async": host_async_us, "value": B / (host_us * 1e-6),
+                                      "unit": "env-steps/s",
+                                      "what": "step_async + step_wait (sg_step_begin / sg_step_end) with NumPy arrays over page-locked "
+                                              "memory, no copies on the host side, no terminal observations: H2D of the actions, the step "
+                                              "kernel, the outputs back in two copies, all enqueued by step_async (us_in_step_async of host "
+                                              "time; the host is free until step_wait); PCIe-inclusive, never `value`"}
+        if world > 1:
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "devices_visible": torch.cuda.device_count(), "ranks": ranks_info,
+                                  "distinct_devices": len({r["device_index"] for r in ranks_info})}
         if gather_ms is not None:
-            out["ms_per_step_with_rccl_gather"] = gather_ms
+            out["ms_per_step_with_rccl_gather"] = gather_ms  # max over ranks; one launch per step + the gather to rank 0
+            out["value_with_rccl_gather"] = world * B / (gather_ms * 1e-3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env, B, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -96,6 +96,22 @@ int sg_step(sg_env *env, const void *actions_host, float *obs_host, float *rewar
 int sg_step_device(sg_env *env, const void *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                    uint8_t *truncated_dev, float *terminal_obs_dev, void *hip_stream);
 
+/* The same step in two halves, for callers that have something else to do while it runs -- gym.vector's
+ * step_async() / step_wait() around SpaceshipEnv.step (spaceship_env.py:68-78).
+ *   sg_step_begin  enqueues, on the handle's stream, the copy of the actions to the device, the step kernel and ONE copy of all
+ *                  its outputs into a page-locked result block owned by the handle, and returns without waiting.
+ *                  `actions_host` must stay unchanged until sg_step_end (page-locked memory, sg_host_alloc, makes the copy a
+ *                  plain DMA).  want_terminal_obs != 0 adds the terminal observations to the block (rows of envs that did
+ *                  not finish read NaN).
+ *   sg_step_end    waits for that step and returns pointers into its result block: obs [num_envs, obs_dim], reward, done,
+ *                  truncated as in sg_step, terminal_obs or NULL (any out pointer may be NULL).  The handle alternates
+ *                  between two blocks: the pointers stay valid until the sg_step_end after next, so the results of step t can
+ *                  be read while step t + 1 is in flight.
+ * One step may be in flight per handle; any other call on the handle between the two is ordered behind the step. */
+int sg_step_begin(sg_env *env, const void *actions_host, int32_t want_terminal_obs);
+int sg_step_end(sg_env *env, const float **obs, const float **reward, const uint8_t **done, const uint8_t **truncated,
+                const float **terminal_obs);
+
 /* `n_steps` consecutive steps for pre-supplied actions (open-loop rollout, e.g. random-action benchmarking or replaying an
  * action tape): actions [n_steps, num_envs, 2] (discrete ids: int32 [n_steps, num_envs]), obs [n_steps, num_envs, obs_dim], reward/done/truncated [n_steps, num_envs].
  * Bit-identical to n_steps calls of sg_step_device.  All steps run in ONE kernel launch with the env state held in

@@ -40,6 +40,8 @@ SYMBOLS = {
     "sg_reset_device": (C.c_int, [_vp, _vp, _vp]),
     "sg_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sg_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sg_step_begin": (C.c_int, [_vp, _vp, C.c_int32]),
+    "sg_step_end": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "sg_rollout_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sg_set_unfused_rollout": (C.c_int, [_vp, C.c_int32]),
     "sg_rollout_device_terminal": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.POINTER(SgTerminalList), _vp]),

@@ -4,10 +4,11 @@ Envs never interact (gym_space/dynamic_model.py:145-165 sums only an env's own p
 contiguous blocks -- rank k owns global envs [k*B/W, (k+1)*B/W) -- and `step_local` involves no communication at all.
 The RNG is keyed by the GLOBAL env index (sg_config.env_index_base), so results do not depend on the number of ranks.
 
-Only the single-process VectorEnv view needs a collective: `step(actions)` scatters rank 0's actions ([B, 2] float32, or [B]
-int32 indices for the discrete ids) and gathers one packed buffer per rank -- obs | [terminal obs] | reward | done |
-truncated -- back to rank 0 (a rooted gather: on the fully connected xGMI mesh every peer uses its own link to the root
-once; no ring, no all-reduce).
+Only the single-process VectorEnv view needs an exchange: `step(actions)` scatters rank 0's actions ([B, 2] float32, or [B]
+int32 indices for the discrete ids) and gathers every rank's (obs, [terminal obs], reward, done, truncated) into rank 0's
+result arrays -- allocated once, [B, ...] each; the peers' blocks are received straight into their slices (one batch of
+point-to-point transfers per step: on the fully connected xGMI mesh every peer uses its own link to the root; no ring, no
+all-reduce, no concatenation on the root).  What step() returns on rank 0 are those arrays: valid until the next call.
 """
 import numpy as np
 import torch
@@ -19,39 +20,6 @@ def shard_bounds(num_envs, world_size, rank):
     base, rem = divmod(int(num_envs), int(world_size))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
-
-
-class PackedResult:
-    """obs f32 [n, D] | (terminal obs f32 [n, D]) | reward f32 [n] | done u8 [n] | truncated u8 [n] in ONE flat uint8
-    buffer (one message per rank)."""
-
-    def __init__(self, n, obs_dim, device, with_terminal=False):
-        self.n, self.d, self.with_terminal = n, obs_dim, bool(with_terminal)
-        self.nbytes = self.size(n, obs_dim, with_terminal)
-        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
-
-    @staticmethod
-    def size(n, d, with_terminal=False):
-        return 4 * n * d * (2 if with_terminal else 1) + 4 * n + 2 * n
-
-    @staticmethod
-    def views(buf, n, d, with_terminal=False):
-        """(obs, reward, done, truncated[, terminal obs]) views into a packed buffer"""
-        o_end = 4 * n * d
-        t_end = o_end + (4 * n * d if with_terminal else 0)
-        r_end = t_end + 4 * n
-        out = (buf[:o_end].view(torch.float32).view(n, d), buf[t_end:r_end].view(torch.float32),
-               buf[r_end:r_end + n], buf[r_end + n:r_end + 2 * n])
-        if with_terminal:
-            out += (buf[o_end:t_end].view(torch.float32).view(n, d),)
-        return out
-
-    def fill(self, obs, reward, done, trunc, tobs=None):
-        v = self.views(self.buf, self.n, self.d, self.with_terminal)
-        v[0].copy_(obs); v[1].copy_(reward); v[2].copy_(done.to(torch.uint8)); v[3].copy_(trunc.to(torch.uint8))
-        if self.with_terminal:
-            v[4].copy_(tobs)
-        return self.buf
 
 
 class ShardedVectorEnv:
@@ -83,11 +51,14 @@ class ShardedVectorEnv:
         self.local = local_env
         self.obs_dim = local_env.obs_dim
         self.discrete = bool(getattr(local_env, "discrete", False))
-        self._packed = PackedResult(self.n_local, self.obs_dim, self.device, self.with_terminal)
-        self._gather_bufs = None
+        # rank 0's result arrays for all envs, allocated once; each rank's block is received straight into its slice
+        self._fields = None
         if self.rank == 0:
-            self._gather_bufs = [torch.empty(PackedResult.size(hi - lo, self.obs_dim, self.with_terminal), dtype=torch.uint8,
-                                             device=self.device) for lo, hi in self.counts]
+            B, D, dev = self.num_envs, self.obs_dim, self.device
+            self._fields = [torch.empty((B, D), dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
+                            torch.empty(B, dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.uint8, device=dev)]
+            if self.with_terminal:
+                self._fields.append(torch.empty((B, D), dtype=torch.float32, device=dev))
         # the env's action spec: one int32 index per env for the discrete ids (spaceship_env.py:183-202), else float32 [2]
         self._act_dtype = torch.int32 if self.discrete else torch.float32
         self._act_shape = (self.n_local,) if self.discrete else (self.n_local, 2)
@@ -102,25 +73,21 @@ class ShardedVectorEnv:
 
     # ---- single-process view on rank 0
     def _gather(self, obs, reward, done, trunc, tobs=None):
-        buf = self._packed.fill(obs, reward, done, trunc, tobs)
-        if self.world == 1:
-            parts = [buf]
-        elif _equal_sizes(self.counts):
-            dist.gather(buf, self._gather_bufs if self.rank == 0 else None, dst=0, group=self.group)
-            parts = self._gather_bufs
-        else:  # ragged shards: point-to-point into the root
-            if self.rank == 0:
-                self._gather_bufs[0].copy_(buf)
-                reqs = [dist.irecv(self._gather_bufs[r], src=r, group=self.group) for r in range(1, self.world)]
-                for q in reqs:
-                    q.wait()
-            else:
-                dist.send(buf, dst=0, group=self.group)
-            parts = self._gather_bufs
-        if self.rank != 0:
-            return None
-        outs = [PackedResult.views(p, hi - lo, self.obs_dim, self.with_terminal) for p, (lo, hi) in zip(parts, self.counts)]
-        return tuple(torch.cat([o[k] for o in outs]) for k in range(5 if self.with_terminal else 4))
+        """every rank's block of every field into rank 0's [num_envs, ...] arrays: ONE batch of point-to-point transfers
+        (a single grouped launch with the nccl backend), received in place -- nothing is concatenated or re-packed"""
+        local = [obs, reward, done.to(torch.uint8), trunc.to(torch.uint8)] + ([tobs] if self.with_terminal else [])
+        local = [x.contiguous() for x in local]
+        if self.rank == 0:
+            lo, hi = self.counts[0]
+            for dst, src in zip(self._fields, local):
+                dst[lo:hi].copy_(src)
+            ops = [dist.P2POp(dist.irecv, f[lo:hi], r, self.group) for r, (lo, hi) in enumerate(self.counts) if r for f in self._fields]
+        else:
+            ops = [dist.P2POp(dist.isend, x, 0, self.group) for x in local]
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        return tuple(self._fields) if self.rank == 0 else None
 
     def reset(self):
         obs = self.local.reset_tensors()

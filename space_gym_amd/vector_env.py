@@ -7,7 +7,10 @@ Mirrors the reference's env surface for the step path -- `reset() -> obs`, `step
 auto-reset, all inside the step kernel.
 
 Two I/O modes:
-  * NumPy (`reset`, `step`): host arrays in/out through sg_step (H2D + kernel + D2H per call);
+  * NumPy (`reset`, `step` = `step_async` + `step_wait`): host arrays in/out (H2D + kernel + D2H per step).  step_async
+    enqueues all of it (sg_step_begin) and returns; step_wait waits (sg_step_end) and hands out the step's results, which
+    sit in one of two page-locked blocks that alternate -- with copy=False the arrays of step t stay valid while step t + 1
+    is in flight;
   * torch (`reset_torch`, `step_torch`, `rollout_torch`): device tensors in/out through sg_step_device on torch's
     current stream, zero-copy -- the high-throughput path.
 """
@@ -63,15 +66,10 @@ class SpaceGymVectorEnv:
         B, D = self.num_envs, self.obs_dim
         self.copy = bool(copy)
         self._pinned = []
-        self._obs = self._host_array((B, D), np.float32)
-        self._rew = self._host_array((B,), np.float32)
-        self._done = self._host_array((B,), np.uint8)
-        self._trunc = self._host_array((B,), np.uint8)
+        self._obs = self._host_array((B, D), np.float32)  # reset()'s observations (a step's outputs sit in the handle's blocks)
         self._act = self._host_array((B,) if self.discrete else (B, 2), np.int32 if self.discrete else np.float32)
-        self._tobs = self._host_array((B, D), np.float32) if terminal_observation else None
-        if self._tobs is not None:
-            self._tobs.fill(np.nan)
-        self._pending = None
+        self._pending = False
+        self._blocks = {}
         self._torch_bufs = None
 
     def _host_array(self, shape, dtype):
@@ -88,7 +86,8 @@ class SpaceGymVectorEnv:
         if getattr(self, "_h", None):
             self._lib.sg_destroy(self._h)
             self._h = None
-            self._obs = self._rew = self._done = self._trunc = self._act = self._tobs = None
+            self._obs = self._act = None
+            self._blocks = {}
             for ptr in self._pinned:
                 self._lib.sg_host_free(ptr)
             self._pinned = []
@@ -136,22 +135,40 @@ class SpaceGymVectorEnv:
         return actions
 
     def step_async(self, actions):
-        self._pending = self._check_actions(actions)
+        """gym.vector's step_async: everything the step needs is enqueued on the engine's stream -- the actions' copy to the
+        device, the step kernel, ONE copy of all its outputs back -- and the call returns; step_wait() collects."""
+        if self._pending:
+            raise RuntimeError("step_async() while a step is in flight (step_wait() first)")
+        np.copyto(self._act, self._check_actions(actions))  # into the pinned action buffer (unchanged until step_wait)
+        self._ck(self._lib.sg_step_begin(self._h, self._ptr(self._act), int(self.want_terminal_obs)), "sg_step_begin")
+        self._pending = True
+
+    def _block_views(self, ptrs):
+        """NumPy views of one of the handle's two result blocks (made once per block)"""
+        key = ptrs[0]
+        if key not in self._blocks:
+            B, D = self.num_envs, self.obs_dim
+
+            def view(ptr, shape, dtype):
+                n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                return np.frombuffer((C.c_char * n).from_address(ptr), dtype=dtype).reshape(shape)
+            self._blocks[key] = (view(ptrs[0], (B, D), np.float32), view(ptrs[1], (B,), np.float32), view(ptrs[2], (B,), np.uint8),
+                                 view(ptrs[3], (B,), np.uint8), view(ptrs[4], (B, D), np.float32) if ptrs[4] else None)
+        return self._blocks[key]
 
     def step_wait(self):
-        a, self._pending = self._pending, None
-        if a is None:
+        if not self._pending:
             raise RuntimeError("step_wait() without step_async()")
-        np.copyto(self._act, a)  # into the pinned action buffer
-        rc = self._lib.sg_step(self._h, self._ptr(self._act), self._ptr(self._obs), self._ptr(self._rew),
-                               self._ptr(self._done), self._ptr(self._trunc), self._ptr(self._tobs))
-        self._ck(rc, "sg_step")
-        info = StepInfo({"TimeLimit.truncated": self._trunc.view(np.bool_) if not self.copy else self._trunc.astype(bool)})
-        if self._tobs is not None:
-            info["terminal_observation"] = self._tobs.copy() if self.copy else self._tobs
+        self._pending = False
+        p = [C.c_void_p() for _ in range(5)]
+        self._ck(self._lib.sg_step_end(self._h, *[C.byref(x) for x in p]), "sg_step_end")
+        obs, rew, done, trunc, tobs = self._block_views([x.value for x in p])
+        info = StepInfo({"TimeLimit.truncated": trunc.view(np.bool_) if not self.copy else trunc.astype(bool)})
+        if tobs is not None:
+            info["terminal_observation"] = tobs.copy() if self.copy else tobs
         if self.copy:
-            return self._obs.copy(), self._rew.copy(), self._done.astype(bool), info
-        return self._obs, self._rew, self._done.view(np.bool_), info
+            return obs.copy(), rew.copy(), done.astype(bool), info
+        return obs, rew, done.view(np.bool_), info
 
     def step(self, actions):
         self.step_async(actions)

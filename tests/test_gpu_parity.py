@@ -239,6 +239,46 @@ def test_device_tensor_path_matches_host_path():
     e1.close(); e2.close()
 
 
+@pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "KeplerDiscrete-v0"])
+def test_step_async_wait_pair_and_raw_begin_end(env_id):
+    """step_async() + step_wait() (sg_step_begin / sg_step_end: the step in two halves, its outputs in one of two page-locked
+    blocks that alternate) against the one-call sg_step through raw ctypes: same outputs step for step incl. terminal
+    observations; with copy=False the arrays of step t stay intact while step t + 1 is in flight; misuse raises."""
+    import ctypes as C
+    n, K = 4096, 60
+    rng = np.random.default_rng(3)
+    env = make(env_id, n, seed=9, max_episode_steps=25, copy=False)
+    ref = make(env_id, n, seed=9, max_episode_steps=25)
+    D = env.obs_dim
+    assert np.array_equal(env.reset(), ref.reset())
+    with pytest.raises(RuntimeError):
+        env.step_wait()
+    prev = None
+    n_done = 0
+    for t in range(K):
+        a = rng.integers(0, 6, n).astype(np.int32) if env.discrete else rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        env.step_async(a)
+        with pytest.raises(RuntimeError):
+            env.step_async(a)
+        # reference: the one-call entry point, host arrays, through raw ctypes
+        o2, r2 = np.empty((n, D), np.float32), np.empty(n, np.float32)
+        d2, t2, to2 = np.empty(n, np.uint8), np.empty(n, np.uint8), np.full((n, D), np.nan, np.float32)
+        a2 = np.ascontiguousarray(a)
+        rc = ref._lib.sg_step(ref._h, *[x.ctypes.data_as(C.c_void_p) for x in (a2, o2, r2, d2, t2, to2)])
+        assert rc == 0
+        if prev is not None:  # the previous step's arrays (views of the other block) are untouched by the step in flight
+            assert all(np.array_equal(x, y) for x, y in zip(prev[0], prev[1]))
+        obs, rew, done, info = env.step_wait()
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(done, d2.astype(bool))
+        assert np.array_equal(info["TimeLimit.truncated"], t2.astype(bool))
+        tobs = info["terminal_observation"]
+        assert np.array_equal(tobs[done], to2[done]) and np.isnan(tobs[~done]).all()
+        prev = ((obs, rew, done), (obs.copy(), rew.copy(), done.copy()))
+        n_done += int(done.sum())
+    assert n_done > n
+    env.close(); ref.close()
+
+
 @pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerCircleOrbit-v0",
                                     "KeplerRandomOrbits-v0", "GoalDiscrete3-v0", "KeplerDiscrete-v0"])
 def test_fused_rollout_equals_step_by_step(env_id):

@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: world_size-2 (and 3, ragged) gloo process groups exercise the env sharding, the action scatter and the
-packed (obs | reward | done | truncated) gather of space_gym_amd/sharded.py.  The per-rank engine is GPU-only, so the
+"""N > 1 path on CPU: world_size-2 (and 3, ragged; 8) gloo process groups exercise the env sharding, the action scatter and the
+gather of (obs, reward, done, truncated[, terminal obs]) into rank 0's preallocated arrays of space_gym_amd/sharded.py.  The per-rank engine is GPU-only, so the
 ranks drive the CPU oracle as a stand-in local engine (tests may use the oracle); the check is that the sharded run equals
 a single-process run of the full batch, env for env -- which also pins that the RNG is keyed by the GLOBAL env index."""
 import os
@@ -59,9 +59,16 @@ def _worker(rank, world, port, out_path, env_id, with_terminal):
     eng = OracleLocalEngine(env_id, hi - lo, SEED, lo, max_episode_steps=12, with_terminal=with_terminal)
     env = ShardedVectorEnv(env_id, NUM_ENVS, seed=SEED, local_env=eng, device="cpu", terminal_observation=with_terminal)
     assert (env.lo, env.hi) == (lo, hi) and env.discrete == ("Discrete" in env_id)
-    trace = [env.reset()]
+    def keep(res):  # (rank 0's results are its preallocated arrays: valid until the next call)
+        return None if res is None else res.clone() if torch.is_tensor(res) else tuple(x.clone() for x in res)
+    trace = [keep(env.reset())]
+    first = None
     for t in range(STEPS):
-        trace.append(env.step(_actions(t, env.discrete) if rank == 0 else None))
+        res = env.step(_actions(t, env.discrete) if rank == 0 else None)
+        if rank == 0:
+            first = first or [x.data_ptr() for x in res]
+            assert [x.data_ptr() for x in res] == first  # no per-step allocation or concatenation on the root
+        trace.append(keep(res))
     if rank == 0:
         assert all(len(step) == (5 if with_terminal else 4) for step in trace[1:])
         np.savez(out_path, reset_obs=trace[0].numpy(), **{f"{k}{t}": v.numpy() for t, step in enumerate(trace[1:])
