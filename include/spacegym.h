@@ -143,6 +143,17 @@ int sg_rollout_device_terminal(sg_env *env, int32_t n_steps, const void *actions
  * sg_check_status -- which waits for the work enqueued so far, reports the condition and clears it -- has been called. */
 int sg_check_status(sg_env *env);
 
+/* Event counters of a handle (SURVEY section 5 "metrics"; the reference itself only keeps KeplerEnv's last penalties as
+ * attributes, kepler.py:146-149): env-steps taken, episodes finished (terminal event or truncation), truncations
+ * (gym.wrappers.TimeLimit), goals reached (GoalEnv._reward's `goal_pos` test, goal.py:154-157; 0 for the Kepler ids) since
+ * counting was switched on or last reset.  Off by default -- the step and rollout kernels then do nothing for it; on, every
+ * step / rollout call is followed by a pass over the done / truncated flags it wrote, and the reward code adds its goal hits. */
+typedef struct sg_counters {
+    uint64_t env_steps, episodes_finished, truncations, goal_hits;
+} sg_counters;
+int sg_set_counters(sg_env *env, int32_t on);                              /* switching (on or off) zeroes the counters */
+int sg_get_counters(sg_env *env, sg_counters *out, int32_t reset);         /* waits for the enqueued work first */
+
 /* On-device action source for sg_rollout_device: the uniformly random policy (what the reference's README loop and the
  * benchmark use: env.action_space.sample(), gym spaces Box / Discrete).  Fills actions_dev [n_steps, num_envs, 2] float32
  * with i.i.d. U(-1, 1) values (discrete ids: int32 [n_steps, num_envs] uniform in 0..5).  Entry (t, i) is a function of

@@ -19,6 +19,10 @@ class SgTerminalList(C.Structure):
     _fields_ = [("count", C.c_void_p), ("step_env", C.c_void_p), ("obs", C.c_void_p), ("capacity", C.c_uint32)]
 
 
+class SgCounters(C.Structure):
+    _fields_ = [("env_steps", C.c_uint64), ("episodes_finished", C.c_uint64), ("truncations", C.c_uint64), ("goal_hits", C.c_uint64)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -46,6 +50,8 @@ SYMBOLS = {
     "sg_set_unfused_rollout": (C.c_int, [_vp, C.c_int32]),
     "sg_rollout_device_terminal": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.POINTER(SgTerminalList), _vp]),
     "sg_check_status": (C.c_int, [_vp]),
+    "sg_set_counters": (C.c_int, [_vp, C.c_int32]),
+    "sg_get_counters": (C.c_int, [_vp, C.POINTER(SgCounters), C.c_int32]),
     "sg_state_bytes": (C.c_size_t, [_vp]),
     "sg_save_state": (C.c_int, [_vp, _vp, C.c_size_t]),
     "sg_load_state": (C.c_int, [_vp, _vp, C.c_size_t]),

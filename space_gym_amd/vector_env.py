@@ -107,6 +107,15 @@ class SpaceGymVectorEnv:
         self._ck(self._lib.sg_seed(self._h, seed), "sg_seed")
         return [seed]
 
+    def set_counters(self, on=True):
+        """per-batch event counters (sg_set_counters): env-steps, finished episodes, truncations, goals reached; off by default"""
+        self._ck(self._lib.sg_set_counters(self._h, int(bool(on))), "sg_set_counters")
+
+    def counters(self, reset=False):
+        k = _native.SgCounters()
+        self._ck(self._lib.sg_get_counters(self._h, C.byref(k), int(bool(reset))), "sg_get_counters")
+        return {f: int(getattr(k, f)) for f, _ in k._fields_}
+
     def set_auto_reset(self, on):
         self._ck(self._lib.sg_set_auto_reset(self._h, int(bool(on))), "sg_set_auto_reset")
 

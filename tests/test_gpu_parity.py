@@ -360,7 +360,8 @@ def _fused_vs_step_by_step(env_id, max_episode_steps=120, K=300, split=100, auto
     _assert_same_rollout(n, o1, r1, d1, t1, s1, o2, r2, d2, t2, s2, restarts=auto_reset)
 
 
-@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "GoalDiscrete3-v0"])
+@pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "GoalContinuous4P-v0", "GoalDiscrete3-v0",
+                                    "KeplerCircleOrbit-v0", "KeplerRandomOrbits-v0", "KeplerDiscrete-v0"])
 def test_pair_step_kernel_equals_step_kernel(env_id, monkeypatch):
     """the one-launch-per-step kernel with pilot + finisher wave pairs (next episodes generated by the one-lane reset while
     the pilot integrates) gives the same bits as the one-wave kernel (8-lane cooperative restart): every output of every

@@ -87,6 +87,49 @@ def test_pair_rollout_matches_oracle_directly(env_id, n, K):
     ref_env.close()
 
 
+@pytest.mark.parametrize("kernel", ["pair", "single", "steps"])
+def test_event_counters_match_outputs_and_oracle(kernel, monkeypatch):
+    """sg_set_counters / sg_get_counters: env-steps, finished episodes and truncations equal the sums of the flags the steps
+    wrote; goals reached equal the oracle's goal-hit flags on the same transitions (terminal steps included) -- for the
+    wave-pair rollout kernel (hits of replayed terminal steps are counted by their replay), the one-wave rollout kernel and
+    one launch per step."""
+    import torch
+    env_id, n, K, pre = "GoalContinuous3P-v0", 4096, 50, 30
+    if kernel != "steps":
+        monkeypatch.setenv("SPACEGYM_ROLLOUT_KERNEL", kernel)
+    a = torch.rand((pre + K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(6)) * 2 - 1
+    env = make(env_id, n, seed=3, max_episode_steps=45)
+    env.set_unfused_rollout(kernel == "steps")
+    env.reset_torch()
+    obs, rew, done, trunc = _rollout_buffers(env, pre + K)
+    env.rollout_torch(a[:pre], obs[:pre], rew[:pre], done[:pre], trunc[:pre])
+    assert env.counters() == dict(env_steps=0, episodes_finished=0, truncations=0, goal_hits=0)  # off: nothing is counted
+    env.set_counters(True)
+    env.rollout_torch(a[pre:], obs[pre:], rew[pre:], done[pre:], trunc[pre:])
+    k = env.counters()
+    env.close()
+    assert k["env_steps"] == n * K
+    assert k["episodes_finished"] == int(done[pre:].sum()) and k["truncations"] == int(trunc[pre:].sum()) and k["truncations"] > 0
+    # the oracle's goal hits on the same transitions: a twin handle stepped one launch at a time gives the pre-step states
+    ref_env = make(env_id, n, seed=3, max_episode_steps=45)
+    ref_env.set_counters(True)
+    o = Oracle(env_id, threads=16)
+    ref_env.reset()
+    a_h = a.cpu().numpy()
+    hits = 0
+    for t in range(pre + K):
+        st = ref_env.get_state()
+        if t == pre:
+            ref_env.counters(reset=True)
+        ref_env.step(a_h[t])
+        if t >= pre:
+            hits += int(o.step(st["ship"].astype(np.float64), a_h[t], st["planets"].astype(np.float64), st["goal"].astype(np.float64))["goal_hit"].sum())
+    k2 = ref_env.counters()
+    ref_env.close()
+    assert k2 == k  # NumPy path, one launch per step: the same counts
+    assert hits > 50 and abs(k["goal_hits"] - hits) <= 2  # (a position within fp32 rounding of the goal radius could flip one)
+
+
 @pytest.mark.parametrize("env_id", ["GoalContinuous2P-v0", "GoalContinuous3P-v0", "KeplerEllipseHard-v0"])
 def test_event_roots_on_grazing_and_corner_cases_gpu(env_id):
     """the adversarial terminal steps of tests/test_host_twin.py on the card (v_rsq / v_rcp / v_log / v_exp instead of libm):

@@ -42,12 +42,13 @@ def main():
     for k, name in PILOT.items():
         print("  %-40s %8.0f" % (name, pil[:, k].mean()))
     print("  %-40s %8.0f" % ("total", sum(pil[:, k].mean() for k in PILOT)))
-    print("  wave-steps with a terminal event %.3f" % pil[:, 7].mean())
+    print("  wave-steps with a terminal event %.3f, with a lane on scipy's sequence %.4f (more than one RK step: %.4f)" % (
+        pil[:, 7].mean(), pil[:, 10].mean(), pil[:, 11].mean()))
     print("finisher waves: cycles per step")
     for k, name in FIN.items():
         print("  %-40s %8.0f" % (name, fin[:, k].mean()))
     print("  %-40s %8.0f" % ("total", sum(fin[:, k].mean() for k in FIN)))
-    print("  queue refills per step %.4f, episodes generated per step %.3f" % (fin[:, 10].mean(), fin[:, 11].mean()))
+    print("  queue refill passes per step %.4f, goal resample passes per step %.4f" % (fin[:, 10].mean(), fin[:, 11].mean()))
 
 
 if __name__ == "__main__":
