@@ -977,25 +977,34 @@ SG_FN uint32_t free_total(uint64_t f) {
     uint64_t s = (f & 0x0f0f0f0f0f0f0f0full) + ((f >> 4) & 0x0f0f0f0f0f0f0f0full);
     return (uint32_t)((s * 0x0101010101010101ull) >> 56);
 }
-// tile at position `pos` of the sorted multiset (pos < total)
-SG_FN uint32_t free_at(uint64_t f, uint32_t pos) {
-    if ((f & 0xEEEEEEEEEEEEEEEEull) == 0) {  // every counter is 0 or 1: the (pos+1)-th set nibble
-        for (uint32_t j = 0; j < pos; j++) f &= f - 1;
-#if defined(__HIP_DEVICE_COMPILE__)
-        return (uint32_t)(__ffsll((long long)f) - 1) >> 2;
-#else
-        return (uint32_t)__builtin_ctzll(f) >> 2;
-#endif
-    }
-    uint32_t tile = 0, acc = 0;
-#pragma unroll
-    for (uint32_t t = 0; t < 16; t++) {
-        uint32_t cnt = (uint32_t)(f >> (4 * t)) & 15u;
-        if (pos >= acc && pos < acc + cnt) tile = t;
-        acc += cnt;
-    }
-    return tile;
+// The multiset as running totals, for looking up the tile at a position without loops or branches (a goal resample looks up
+// three; with a loop over the set counters and a 16-step scan for multisets with duplicates -- both unrolled three times --
+// these look-ups were more than half of the resampling code, which a whole wave runs for the one lane that reached its goal):
+//   even[k] (byte k) = number of entries in tiles 0 .. 2k,   odd[k] = number of entries in tiles 0 .. 2k + 1   (each <= 240)
+struct FreePrefix { uint64_t even, odd; };
+SG_FN FreePrefix free_prefix(uint64_t f) {
+    const uint64_t e = f & 0x0f0f0f0f0f0f0f0full, o = (f >> 4) & 0x0f0f0f0f0f0f0f0full;
+    const uint64_t pe = e * 0x0101010101010101ull, po = o * 0x0101010101010101ull;  // byte k = sum of bytes 0..k (<= 120: no carries)
+    FreePrefix p;
+    p.even = pe + (po << 8);
+    p.odd = pe + po;
+    return p;
 }
+// number of bytes of x that are > pos (pos <= 254; bytes up to 255), by SWAR: a byte is > pos if its high bit says so, or the
+// high bits agree and its low seven bits are > pos's
+SG_FN uint32_t bytes_above(uint64_t x, uint32_t pos) {
+    const uint64_t H = 0x8080808080808080ull, L = 0x0101010101010101ull;
+    const uint64_t low_gt = (((x & ~H) + (uint64_t)(127u - (pos & 127u)) * L) & H);  // low seven bits > pos & 127 (no carries: <= 254)
+    const uint64_t hi = x & H;
+    const uint64_t gt = (pos < 128u) ? (hi | low_gt) : (hi & low_gt);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(gt);
+#else
+    return (uint32_t)__builtin_popcountll(gt);
+#endif
+}
+// tile at position `pos` of the sorted multiset (pos < total): the number of tiles whose running total is <= pos
+SG_FN uint32_t free_at(const FreePrefix &p, uint32_t pos) { return 16u - bytes_above(p.even, pos) - bytes_above(p.odd, pos); }
 SG_FN uint64_t free_add(uint64_t f, uint32_t tile) {
     uint32_t cnt = (uint32_t)(f >> (4 * tile)) & 15u;
     return cnt < 15u ? f + (1ull << (4 * tile)) : f;
@@ -1054,10 +1063,11 @@ SG_FN void choose_goal_tile(const SgDev &c, Tiling &T, bool first, const uint32_
         }
         uint32_t best_tile = 0;
         int best_dist = -1;
+        const FreePrefix fp = free_prefix(T.free_counts);
 #pragma unroll
         for (uint32_t i = 0; i < 3; i++) {  // fully unrolled: keeps chosen[] in registers
             if (i < n_cand) {
-                uint32_t tile = free_at(T.free_counts, chosen[i]);
+                uint32_t tile = free_at(fp, chosen[i]);
                 uint32_t r = (tile * c.t_cols_rcp16) >> 16, cc = tile - r * cols;
                 int dist = abs((int)r - (int)sr) + abs((int)cc - (int)sc);  // :119-121
                 if (dist > best_dist) { best_dist = dist; best_tile = tile; }  // first max, :122-124

@@ -149,6 +149,10 @@ extern "C" int twin_reset(const char *env_id, uint64_t seed, int64_t m, uint32_t
     return 0;
 }
 
+// tile at position `pos` of a free-tile multiset (sixteen 4-bit counters), as goal resampling looks it up; and its size
+extern "C" uint32_t twin_free_at(uint64_t f, uint32_t pos) { return free_at(free_prefix(f), pos); }
+extern "C" uint32_t twin_free_total(uint64_t f) { return free_total(f); }
+
 extern "C" void twin_philox(uint32_t k0, uint32_t k1, const uint32_t *ctr, uint32_t *out) {
     uint32_t o[4];
     philox4x32_10(k0, k1, ctr[0], ctr[1], ctr[2], ctr[3], o);

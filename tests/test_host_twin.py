@@ -109,6 +109,33 @@ def test_probe_step_stays_within_tolerance_and_scipy_build_follows_step_counts(e
     assert kept > 2500  # (scipy splits about a fifth of the random transitions; the probe step covers 99 % of them)
 
 
+def test_free_tile_lookup_matches_definition():
+    """HexagonalTiling's free-tile list as a sorted multiset of sixteen 4-bit counters (hexagonal_tiling.py:91,101-106,126):
+    the engine finds the tile at a position without loops or branches (running totals + a byte-wise compare); against the
+    plain definition on random multisets, duplicates up to the counters' saturation included."""
+    import ctypes as C
+    from pytwin import Twin
+    lib = Twin("GoalContinuous4P-v0").lib
+    lib.twin_free_at.argtypes, lib.twin_free_at.restype = [C.c_uint64, C.c_uint32], C.c_uint32
+    lib.twin_free_total.argtypes, lib.twin_free_total.restype = [C.c_uint64], C.c_uint32
+    rng = np.random.default_rng(0)
+    checked = 0
+    for mode, hi in ((0, 2), (1, 4), (2, 16)) * 4000:
+        nt = int(rng.integers(4, 17))
+        cnt = np.zeros(16, np.int64)
+        cnt[:nt] = rng.integers(0, hi, nt)
+        total = int(cnt.sum())
+        if total == 0:
+            continue
+        f = int(sum(int(c) << (4 * t) for t, c in enumerate(cnt)))
+        assert lib.twin_free_total(f) == total
+        expanded = np.repeat(np.arange(16), cnt)
+        for pos in {0, total - 1, int(rng.integers(0, total))}:
+            assert lib.twin_free_at(f, pos) == expanded[pos], (hex(f), pos)
+            checked += 1
+    assert checked > 20000
+
+
 def test_philox_known_answers():
     """Random123 known-answer vectors for philox4x32-10, on the oracle and on the engine's device code."""
     o, t = Oracle("GoalContinuous2P-v0"), Twin("GoalContinuous2P-v0")
