@@ -885,7 +885,9 @@ SG_FN float goal_reward(const CFG &c, float x0, float y0, double dX, double dY, 
 // ------------------------------------------------------------------------------------------------
 struct Orbit { double a, b, c, ecc, cosphi, sinphi, a_over_b, b_over_a, inv_a; };
 
-SG_FN float kepler_reward(const SgDev &c, const Orbit &ob, float x0, float y0, double dX, double dY, float vx, float vy,
+// (CFG: the parameter block, or KeplerStepConsts -- the fields used here and in kepler_observe, kept in registers by a K-step loop)
+template <typename CFG>
+SG_FN float kepler_reward(const CFG &c, const Orbit &ob, float x0, float y0, double dX, double dY, float vx, float vy,
                           float engine, float thruster) {
     const double x = (double)x0 + dX, y = (double)y0 + dY;
     // _rotate(pos, phi) (kepler.py:51-58), then shift by the focal distance (kepler.py:68-73)
@@ -1266,7 +1268,8 @@ SG_FN void goal_observe(const CFG &c, const GoalEnv<N> &e, float (&obs)[7 + 2 * 
     obs[8 + 2 * N] = (e.gy - e.y) * c.two_over_world;
 }
 
-SG_FN void kepler_observe(const SgDev &c, const KeplerEnv &e, float (&obs)[10]) {
+template <typename CFG>
+SG_FN void kepler_observe(const CFG &c, const KeplerEnv &e, float (&obs)[10]) {
     float s, co;
     sincos_acc(e.th, s, co);
     obs[0] = e.x; obs[1] = e.y; obs[2] = co; obs[3] = s; obs[4] = e.vx; obs[5] = e.vy; obs[6] = e.om;
@@ -1300,6 +1303,19 @@ SG_FN GoalStepConsts goal_step_consts(const SgDev &c) {
     GoalStepConsts k;
     k.goal_r2 = c.goal_r2; k.danger_r2 = c.danger_r2; k.survival = c.survival; k.goal_scale = c.goal_scale;
     k.safety_scale = c.safety_scale; k.sparse = c.sparse; k.planet_r = c.planet_r; k.two_over_world = c.two_over_world;
+    return k;
+}
+
+// The same for Kepler (kepler_reward, kepler_observe)
+struct KeplerStepConsts {
+    double k_gm, k_C, k_Cr, k_phi, k_ecc, k_a;
+    float k_Ca;
+    int32_t randomize_orbit;
+};
+SG_FN KeplerStepConsts kepler_step_consts(const SgDev &c) {
+    KeplerStepConsts k;
+    k.k_gm = c.k_gm; k.k_C = c.k_C; k.k_Cr = c.k_Cr; k.k_phi = c.k_phi; k.k_ecc = c.k_ecc; k.k_a = c.k_a; k.k_Ca = c.k_Ca;
+    k.randomize_orbit = c.randomize_orbit;
     return k;
 }
 
