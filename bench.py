@@ -136,6 +136,7 @@ def main():
                     "truncated) to rank 0 (the single-process VectorEnv view: the only exchange the path has)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the NumPy host-buffer path sample (sg_step, PCIe-inclusive)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the one-launch-per-step chain")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,6 +279,27 @@ def main():
         sync_all()
         u_launches, u_ms, u_min, u_max = env.get_profile()
         env.set_profiling(False)
+    # ---- the same chain of step-kernel launches captured once into a hipGraph and replayed (what a policy-in-the-loop user does
+    # with the policy's kernels in between): launch entry and completion of neighbouring kernels overlap as far as the hardware lets them
+    graph_ms = None
+    if world == 1 and not args.no_graph:
+        Kg = min(K, 50)
+        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                env.rollout_torch(act_seq[:Kg], obs[:Kg], rew[:Kg], done[:Kg], trunc[:Kg])
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(3):
+            g.replay()
+        sync_all()
+        t_g = time.perf_counter()
+        n_rep = max(1, 200 // Kg)
+        for _ in range(n_rep):
+            g.replay()
+        sync_all()
+        graph_ms = (time.perf_counter() - t_g) * 1e3 / (n_rep * Kg)
+        del g
     env.set_unfused_rollout(False)
 
     # ---- N > 1: the same steps with the only exchange the path has -- every rank's (obs, reward, done, truncated) of each step
@@ -377,6 +399,8 @@ def main():
         out["ms_per_step_median"] = sorted(out["ms_per_step_repeats"])[len(repeats) // 2]
         out["value_one_launch_per_step"] = world * B * K / dt_unfused
         out["ms_per_step_one_launch_per_step"] = dt_unfused * 1e3 / K
+        if graph_ms is not None:  # the same launches replayed from one hipGraph (wall per step)
+            out["ms_per_step_one_launch_per_step_hipgraph"] = graph_ms
         if timing and u_launches:
             u_avg = u_ms * 1e3 / u_launches
             u_ach = B * bytes_per / (u_avg * 1e-6) / 1e9
