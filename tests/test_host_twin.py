@@ -66,12 +66,14 @@ def test_short_sincos_is_exact_to_fp32_rounding_on_its_interval():
 
 @pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "KeplerEllipseHard-v0"])
 def test_probe_step_stays_within_tolerance_and_scipy_build_follows_step_counts(env_id):
-    """The engine tries every env-step as ONE Dormand-Prince step first (Integrator::attempt, the probe step) and keeps it when
+    """The engine tries every env-step as ONE step first -- with Steering.velocity the fast step (Integrator::fast_step:
+    Nystrom's fifth-order method on the gravity, the thrust integrated in closed form; in two halves where its error indicator
+    asks for it), with Steering.acceleration a Dormand-Prince step (Integrator::attempt, the probe step) -- and keeps it when
     its error estimates are far below the tolerance and no event can have happened; everything else -- and every terminal
     state -- follows scipy's own step sequence.  Decisions (done, event index) are the oracle's, states / observations /
     rewards within the stated tolerances, on random transitions and on the adversarial terminal cases; only the accepted-step
-    count may be lower than scipy's, and only for kept probe steps.  Built with -DSG_PROBE_NORM=0.0f (probe off) the same
-    source reproduces scipy's step counts exactly."""
+    count may be lower than scipy's, and only for kept steps, whose error indicator is below the family's bound.  Built with
+    -DSG_PROBE_NORM=0.0f (no step tried first) the same source reproduces scipy's step counts exactly."""
     o = Oracle(env_id, threads=4)
     t, t_off = Twin(env_id), Twin(env_id, defines=("SG_PROBE_NORM=0.0f",), tag="_noprobe")
     envs, _ = o.vec_reset(20000, seed=7)
@@ -96,8 +98,9 @@ def test_probe_step_stays_within_tolerance_and_scipy_build_follows_step_counts(e
             if which == "scipy":
                 assert (tw["path"] == 4).all() and not probe.any()
             else:
-                kp = tw["path"] == 0  # a kept probe step: one step, never terminal
+                kp = tw["path"] == 0  # a kept step: one step, never terminal, error indicator below the bound
                 assert (n_rk[kp] == 1).all() and not term[kp].any() and not (probe & ~kp).any()
+                assert tw["probe_abs"][kp].max() <= (1.5e-6 if o.is_goal else 1e-5) * 1.001
             if k == 0:  # (the adversarial grazes are not held to scipy's step count by either build)
                 assert ((n_rk == nref) | probe).all()
                 if which == "probe":
