@@ -49,6 +49,13 @@ def main():
         print("  %-40s %8.0f" % (name, fin[:, k].mean()))
     print("  %-40s %8.0f" % ("total", sum(fin[:, k].mean() for k in FIN)))
     print("  queue refill passes per step %.4f, goal resample passes per step %.4f" % (fin[:, 10].mean(), fin[:, 11].mean()))
+    # which phase makes the slowest waves slow: the 1 % of the waves with the longest step loops against the average wave
+    for name, w, phases in (("pilot", pil, PILOT), ("finisher", fin, FIN)):
+        tot = sum(w[:, k] for k in phases)
+        slow = np.argsort(-tot)[: max(1, len(tot) // 100)]
+        print("%s: slowest 1 %% of the waves, cycles per step above the average wave (total %+.0f)" % (name, tot[slow].mean() - tot.mean()))
+        for k, nm in phases.items():
+            print("  %-40s %+8.0f" % (nm, w[slow, k].mean() - w[:, k].mean()))
 
 
 if __name__ == "__main__":
