@@ -328,13 +328,13 @@ def test_host_calls_are_ordered_after_device_calls():
 
 
 def test_large_batch_plan_branch_4p():
-    """config 5's per-GPU plan at its real size on one card: GoalContinuous4P-v0 with 524 288 envs (2 048 workgroups, more
-    than four per CU: the one-wave rollout kernel with the shallow episode queue).  The fused rollout equals the step
-    kernel bit for bit and the invariants hold."""
+    """config 5's per-GPU plan at its real size on one card: GoalContinuous4P-v0 with 524 288 envs (2 048 workgroups, eight
+    per CU: the wave-pair rollout kernel's workgroups take turns on the CUs, one at a time each).  The fused rollout equals
+    the step kernel bit for bit and the invariants hold."""
     import torch
     n, K = 524288, 24
     env = make("GoalContinuous4P-v0", n, seed=2, max_episode_steps=12)
-    assert env.rollout_kernel(K) == "goal_rollout_kernel<4, false, 2>"
+    assert env.rollout_kernel(K) == "goal_pair_rollout_kernel<4, false, 3, false>"
     a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)) * 2 - 1
     outs = []
     for mode in (0, 1):
