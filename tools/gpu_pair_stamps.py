@@ -14,7 +14,7 @@ import space_gym_amd as sg  # noqa: E402
 from space_gym_amd import _native  # noqa: E402
 
 SLOTS, WAVES = 16, 4096
-PILOT = {0: "top of step (action, waits, loop)", 1: "begin: constants, f(t0), g(t0)", 2: "probe step (+ scipy's sequence)",
+PILOT = {0: "top of step (action, waits, loop)", 1: "begin: constants, f(t0), g(t0)", 2: "fast step (+ scipy's sequence)",
          3: "replay records + state update", 5: "ring record + publish", 8: "TimeLimit + restart"}
 FIN = {0: "loop", 1: "wait for the pilot", 3: "read record, release slot", 4: "reward + update",
        6: "terminal obs (TOBS) + refill passes", 12: "restart: next episode out of the queue", 13: "observation", 5: "output stores",
