@@ -453,45 +453,40 @@ struct Integrator {
 
     // scipy looks at the event functions at the end of each of ITS steps, so it can see a graze that dips below a surface and
     // comes out again within the env-step; a single step over the whole env-step only has the two ends.  It is kept only where
-    // no such dip is possible: a path of length L <= h |v| whose ends are both outside a circle of radius R by d stays outside
-    // if (R + d)^2 - R^2 >= L^2 / 4 -- plus R a h^2 / 4 for the bend an acceleration a gives it (a <= 1.4: engine 0.4, gravity
-    // at a surface <= 1.0) -- and a wall needs a h^2 / 8 of clearance.  (gn: the event functions at the end, as g in begin())
+    // no such dip is possible.  With a = F + 1.1 bounding the acceleration (this step's engine force plus the gravity at a
+    // surface, <= 1.0 + the other planets): a path of length L <= h |v| whose ends are both outside a circle of radius R by d
+    // stays outside if (R + d)^2 - R^2 >= L^2 / 4 + R a h^2 / 4 (chord, plus the bend the acceleration gives it); inside a
+    // circle (Kepler's border) the chord is harmless and R a h^2 / 4 is enough; a wall needs a h^2 / 8.  (20 % on top.)
     // A path that does come that close to a surface still cannot cross it and come back unless its distance to the surface has
-    // an extremum between the two ends.  Circle: the radial velocity u = -(c - p).v / |c - p| changes by at most
-    // (a + v_t^2 / r) per unit time (a <= 1.4, v_t <= |v|), so u(t) >= (u0 + u1) / 2 - (1.4 + |v|^2 / r) h / 2: with both ends
-    // moving the same way and |d0 + d1| > h (1.4 r + |v|^2), d = (c - p).v, the distance is monotonic (r = R: the path is
-    // next to the surface; 20 % margin).  Wall: the same for the velocity component across it, |v0 + v1| > 1.4 h.
-    // Pn: the end position relative to the start.
+    // an extremum between the two ends.  Circle: the radial velocity changes by at most (a + v_t^2 / r) per unit time
+    // (v_t <= |v|), so it keeps its sign if both ends move the same way and |d0 + d1| > h (a r + |v|^2), d = (c - p).v
+    // (r = R: the path is next to the surface).  Wall: the same for the velocity component across it, |v0 + v1| > a h.
+    // gn: the event functions at the end, as g in begin(); Pn: the end position relative to the start.
     SG_MFN bool no_graze(f2 V, f2 Vn, f2 Pn, float h, const float (&gn)[NC + 2]) const {
         const f2 vv0 = V * V, vv1 = Vn * Vn;
         const float v2max = fmaxf(vv0.x + vv0.y, vv1.x + vv1.y);
-        const float clear = fmaf(0.3f * h * h, v2max, 5e-4f);
+        const float ah = 1.2f * h * (F + 1.1f), chord = 0.3f * h * h * v2max;
         bool keep = true;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
             const f2 c = cq_at(k), cn = c - Pn;
             const float d0 = fmaf(c.x, V.x, c.y * V.y), d1 = fmaf(cn.x, Vn.x, cn.y * Vn.y);
-            const bool mono = d0 * d1 > 0.0f && fabsf(d0 + d1) > 1.2f * h * fmaf(1.4f, cR[k], v2max);
+            const bool mono = d0 * d1 > 0.0f && fabsf(d0 + d1) > fmaf(ah, cR[k], 1.2f * h * v2max);
+            const float clear = fmaf(0.25f * h * ah, cR[k], g[k] > 0.0f ? chord : 0.0f);
             const bool near = fminf(fabsf(g[k]), fabsf(gn[k])) <= clear;
             keep = keep && !(near && !mono);
         }
         if (WALLS) {
             const f2 s = V + Vn;
-            const bool mono_x = V.x * Vn.x > 0.0f && fabsf(s.x) > 1.2f * 1.4f * h, mono_y = V.y * Vn.y > 0.0f && fabsf(s.y) > 1.2f * 1.4f * h;
-            const bool near_x = fminf(fminf(wxp, wxp - Pn.x), fminf(wxm, wxm + Pn.x)) <= 1e-3f;
-            const bool near_y = fminf(fminf(wyp, wyp - Pn.y), fminf(wym, wym + Pn.y)) <= 1e-3f;
+            const float clear = 0.125f * h * ah;
+            const bool mono_x = V.x * Vn.x > 0.0f && fabsf(s.x) > ah, mono_y = V.y * Vn.y > 0.0f && fabsf(s.y) > ah;
+            const bool near_x = fminf(fminf(wxp, wxp - Pn.x), fminf(wxm, wxm + Pn.x)) <= clear;
+            const bool near_y = fminf(fminf(wyp, wyp - Pn.y), fminf(wym, wym + Pn.y)) <= clear;
             keep = keep && !(near_x && !mono_x) && !(near_y && !mono_y);
         }
         return keep;
     }
 
-    // The whole env-step as ONE step of Nystrom's fifth-order method with the thrust integrated in closed form (see N5_*):
-    //   x(t) = x0 + t v0 + P(t) + (double integral of the gravity),   P(t) = t^2 (T A(phi) + Tp B(phi)),  phi = omega t,
-    //   A = (1 - cos phi) / phi^2,  B = (phi - sin phi) / phi^2,   T = thrust at t = 0, Tp = T turned by +90 degrees,
-    //   v(t) = v0 + t (T S(phi) + Tp phi A(phi)) + (integral of the gravity),   S = sin phi / phi    (|phi| <= 0.35: series).
-    // Outcomes as for the probe step in attempt(): kept (kRkFinished) | the env-step is terminal (sink, or scipy's sequence
-    // for its terminal state) | not accurate enough or a graze cannot be excluded: kRkContinue after select_initial_step, and
-    // the env-step follows scipy's sequence from t = 0.
     // One step of Nystrom's method over h from the displacement P0 (relative to the start position of the env-step) with
     // velocity V, thrust T (Tp: T turned by +90 degrees) and gravity sum g1 there:  rest = displacement over the step - h V,
     // Vn = the velocity at its end, w = fourth stage position - end position (the error indicator).
