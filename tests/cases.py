@@ -41,6 +41,53 @@ def adversarial_event_cases(o, n=60000, seed=3):
     return s0, a, Pk, gk
 
 
+def tangential_graze_cases(o, n=60000, seed=4):
+    """Stress inputs for the "can a dip between the two ends of the env-step be excluded" decision (Integrator::no_graze):
+    straight paths whose point of closest approach to a planet / the border circle / a wall lies INSIDE the env-step (at
+    0.1..0.9 of it), -0.3..+0.3 mm from the surface (the engine and gravity bend the real path by up to 1 mm: some of these
+    dip below the surface and come out again, some touch, some miss), at 0.15..2.5 units/s.  scipy sees a dip only at the
+    end of one of its own RK steps; the engine has to decide the same.  Same return values as adversarial_event_cases."""
+    rng = np.random.default_rng(seed)
+    envs, _ = o.vec_reset(n, seed=2)
+    h = 0.07
+    tc = rng.uniform(0.1, 0.9, n) * h          # time of closest approach
+    speed = rng.uniform(0.15, 2.5, n)
+    depth = rng.uniform(-3e-4, 3e-4, n)        # > 0: the straight path penetrates the surface by this much
+    ang = rng.uniform(0, 2 * np.pi, n)
+    side = rng.choice([-1.0, 1.0], n)
+    P = g = None
+    if o.is_goal:
+        N, R = o.n_planets, o.params.planet_radius[0]
+        P, g = envs["planets_xy"][:, :N].astype(np.float32), envs["goal_xy"].astype(np.float32)
+        j = rng.integers(0, N, n)
+        nrm = unit(ang)                                           # outward normal at the closest point
+        tan = np.stack([-nrm[:, 1], nrm[:, 0]], -1) * side[:, None]
+        close = P[np.arange(n), j] + nrm * (R - depth)[:, None]
+        w = rng.uniform(size=n) < 0.35                            # walls: closest approach to x or y = +-1.5
+        k = int(w.sum())
+        ax, sg = rng.integers(0, 2, k), rng.choice([-1.0, 1.0], k)
+        cw = rng.uniform(-1.2, 1.2, (k, 2)); cw[np.arange(k), ax] = sg * (1.5 + depth[w])
+        tw_ = np.zeros((k, 2)); tw_[np.arange(k), 1 - ax] = side[w]
+        close[w], tan[w] = cw, tw_
+        pos = close - tan * (speed * tc)[:, None]
+        vel = tan * speed[:, None]
+        ok = np.all(np.abs(pos) < 1.5, axis=1) & (np.linalg.norm(P - pos[:, None], axis=2).min(1) > R)
+    else:
+        inner = rng.uniform(size=n) < 0.5
+        nrm = unit(ang)
+        tan = np.stack([-nrm[:, 1], nrm[:, 0]], -1) * side[:, None]
+        rad = np.where(inner, 0.2 - depth, 3.0 + depth)
+        close = nrm * rad[:, None]
+        pos = close - tan * (speed * tc)[:, None]
+        vel = tan * speed[:, None]
+        r0 = np.linalg.norm(pos, axis=1)
+        ok = (r0 > 0.2) & (r0 < 3.0)
+    s0 = np.concatenate([pos, rng.uniform(0, 2 * np.pi, (n, 1)), vel, rng.normal(size=(n, 1))], 1).astype(np.float32)[ok]
+    a = rng.uniform(-1, 1, (len(s0), 2)).astype(np.float32)
+    Pk, gk = (P[ok], g[ok]) if P is not None else (None, None)
+    return s0, a, Pk, gk
+
+
 def chi2_ok(obs, exp, sigmas=5.0):
     """Pearson chi-square of two count vectors (both sampled): |chi2 - dof| within `sigmas` of its spread."""
     obs, exp = np.asarray(obs, float).ravel(), np.asarray(exp, float).ravel()

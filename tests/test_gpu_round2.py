@@ -153,6 +153,33 @@ def test_event_roots_on_grazing_and_corner_cases_gpu(env_id):
     assert sum(outs) > 150000
 
 
+@pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "GoalContinuous4P-v0", "KeplerEllipseHard-v0"])
+def test_tangential_grazes_decide_like_scipy_gpu(env_id):
+    """tests/test_host_twin.py::test_tangential_grazes_decide_like_scipy on the card: paths that touch a surface in the middle
+    of the env-step (within 0.3 mm), where a step over the whole env-step must not be kept.  Decisions equal the fp64
+    oracle's up to roots that are tangent within fp32 rounding; states and rewards within the tolerances except for a
+    handful of exactly tangent terminal states; non-terminal env-steps all within them."""
+    from cases import tangential_graze_cases
+    o = Oracle(env_id, threads=16)
+    s0, a, P, g = tangential_graze_cases(o, n=60000, seed=4)
+    m = len(s0)
+    env = make(env_id, m, seed=1, auto_reset=False)
+    env.reset()
+    env.set_state(ship=s0, planets=P, goal=g, elapsed=np.zeros(m, np.int32))
+    obs, rew, done, info = env.step(a)
+    s1 = env.get_state()["ship"]
+    env.close()
+    ref = o.step(s0.astype(np.float64), a, None if P is None else P.astype(np.float64), None if g is None else g.astype(np.float64))
+    term = ref["done"] == 1
+    assert 0.2 < term.mean() < 0.9 and m > 30000
+    same = done == ref["done"].astype(bool)
+    assert (~same).sum() <= 2
+    rel = np.abs(rew - ref["reward"])[same] / np.maximum(1, np.abs(ref["reward"][same]))
+    assert (rel > TOL_REWARD_REL).sum() <= 5 and rel.max() <= 1e-4 and not (rel > TOL_REWARD_REL)[~term[same]].any()
+    ds = np.abs(s1[same][:, [0, 1, 3, 4, 5]] - ref["state1"][same][:, [0, 1, 3, 4, 5]]).max(1)
+    assert (ds > TOL_STATE).sum() <= 3 and not (ds > TOL_STATE)[~term[same]].any()
+
+
 @pytest.mark.parametrize("fam", ["goal2p", "goal3p", "goal4p"])
 def test_reset_distribution_matches_reference_gpu(fam):
     """GPU-generated resets and goal-resample chains against the statistics of 1e5 resets of the reference
