@@ -412,9 +412,9 @@ def main():
             out["host_numpy_path"] = {"us_per_step": host_us, "us_in_step_async": host_async_us, "value": B / (host_us * 1e-6),
                                       "unit": "env-steps/s",
                                       "what": "step_async + step_wait (sg_step_begin / sg_step_end) with NumPy arrays over page-locked "
-                                              "memory, no copies on the host side, no terminal observations: H2D of the actions, the step "
-                                              "kernel, the outputs back in two copies, all enqueued by step_async (us_in_step_async of host "
-                                              "time; the host is free until step_wait); PCIe-inclusive, never `value`"}
+                                              "memory, no copies on the host side, no terminal observations: the step kernel reads the actions "
+                                              "from and stores its outputs into page-locked host memory itself, enqueued by step_async "
+                                              "(us_in_step_async of host time; the host is free until step_wait); PCIe-inclusive, never `value`"}
         if world > 1:
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                   "devices_visible": torch.cuda.device_count(), "ranks": ranks_info,

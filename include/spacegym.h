@@ -98,10 +98,10 @@ int sg_step_device(sg_env *env, const void *actions_dev, float *obs_dev, float *
 
 /* The same step in two halves, for callers that have something else to do while it runs -- gym.vector's
  * step_async() / step_wait() around SpaceshipEnv.step (spaceship_env.py:68-78).
- *   sg_step_begin  enqueues, on the handle's stream, the copy of the actions to the device, the step kernel and ONE copy of all
- *                  its outputs into a page-locked result block owned by the handle, and returns without waiting.
- *                  `actions_host` must stay unchanged until sg_step_end (page-locked memory, sg_host_alloc, makes the copy a
- *                  plain DMA).  want_terminal_obs != 0 adds the terminal observations to the block (rows of envs that did
+ *   sg_step_begin  enqueues, on the handle's stream, the step kernel with a page-locked result block owned by the handle as
+ *                  its output (the kernel stores across PCIe itself: no copy commands behind it), and returns without
+ *                  waiting.  `actions_host` must stay unchanged until sg_step_end: page-locked memory (sg_host_alloc) is
+ *                  read by the kernel where it is, anything else is copied to the device first.  want_terminal_obs != 0 adds the terminal observations to the block (rows of envs that did
  *                  not finish read NaN).
  *   sg_step_end    waits for that step and returns pointers into its result block: obs [num_envs, obs_dim], reward, done,
  *                  truncated as in sg_step, terminal_obs or NULL (any out pointer may be NULL).  The handle alternates

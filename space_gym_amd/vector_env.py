@@ -144,8 +144,9 @@ class SpaceGymVectorEnv:
         return actions
 
     def step_async(self, actions):
-        """gym.vector's step_async: everything the step needs is enqueued on the engine's stream -- the actions' copy to the
-        device, the step kernel, ONE copy of all its outputs back -- and the call returns; step_wait() collects."""
+        """gym.vector's step_async: the step kernel is enqueued on the engine's stream -- it reads the actions from the pinned
+        action buffer and stores its outputs into one of the handle's two page-locked result blocks itself -- and the call
+        returns; step_wait() collects."""
         if self._pending:
             raise RuntimeError("step_async() while a step is in flight (step_wait() first)")
         np.copyto(self._act, self._check_actions(actions))  # into the pinned action buffer (unchanged until step_wait)
