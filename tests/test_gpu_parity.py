@@ -239,14 +239,18 @@ def test_device_tensor_path_matches_host_path():
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "KeplerDiscrete-v0"])
-def test_step_async_wait_pair_and_raw_begin_end(env_id):
+@pytest.mark.parametrize("env_id,host_out", [("GoalContinuous3P-v0", "fine"), ("KeplerDiscrete-v0", "fine"),
+                                             ("GoalContinuous3P-v0", "coarse"), ("GoalContinuous3P-v0", "copy")])
+def test_step_async_wait_pair_and_raw_begin_end(env_id, host_out, monkeypatch):
     """step_async() + step_wait() (sg_step_begin / sg_step_end: the step in two halves, its outputs in one of two page-locked
     blocks that alternate) against the one-call sg_step through raw ctypes: same outputs step for step incl. terminal
-    observations; with copy=False the arrays of step t stay intact while step t + 1 is in flight; misuse raises."""
+    observations; with copy=False the arrays of step t stay intact while step t + 1 is in flight; misuse raises.  All three
+    ways the outputs can reach the host: stored by the step kernel into coherent (default) or non-coherent page-locked memory,
+    or into a device block that is copied; with event counters on (which uses the device block) for the second half."""
     import ctypes as C
     n, K = 4096, 60
     rng = np.random.default_rng(3)
+    monkeypatch.setenv("SPACEGYM_HOST_OUT", host_out)  # (read when the handle is created)
     env = make(env_id, n, seed=9, max_episode_steps=25, copy=False)
     ref = make(env_id, n, seed=9, max_episode_steps=25)
     D = env.obs_dim
@@ -256,6 +260,8 @@ def test_step_async_wait_pair_and_raw_begin_end(env_id):
     prev = None
     n_done = 0
     for t in range(K):
+        if t == K // 2:
+            env.set_counters(True)
         a = rng.integers(0, 6, n).astype(np.int32) if env.discrete else rng.uniform(-1, 1, (n, 2)).astype(np.float32)
         env.step_async(a)
         with pytest.raises(RuntimeError):
