@@ -401,7 +401,7 @@ struct Integrator {
         // the probe step comes first; select_initial_step only for the lanes whose probe step is not kept (attempt())
         // (use_probe = false: scipy's sequence straight away -- the replay of an env-step that is known to be terminal)
         probe = kProbeNorm > 0.0f && use_probe;
-        fast = !ACCEL && probe;
+        fast = !ACCEL && probe;  // (its series are for |omega h| <= 0.36: 5 x 0.07 -- sg_create refuses other step sizes)
         probe_crossing = false;
         path = kPathScipy; probe_err = probe_ep = probe_ev = 0.0f;
         if (probe) h_abs = t_end; else initial_step();
