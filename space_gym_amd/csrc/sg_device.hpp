@@ -549,7 +549,9 @@ struct Integrator {
         };
         end_events();
         const float lim = WALLS ? kFastInd : kFastIndKepler;
+        probe_ev = 1.0f;
         if (!(ggmin <= 0.0f) && !(ind2 <= lim * lim)) {
+            probe_ev = 2.0f;
             // Not accurate enough for the reward (a fast pass close to a planet: 0.08 % of the 3P env-steps, 0.5 % of the 4P
             // ones): the same env-step as two steps of half the length -- 1/32 of the error, 1/16 of the indicator -- each
             // held to a quarter of the bound (the velocity between the two is rounded to fp32, 3e-9 of position by itself).
@@ -570,7 +572,7 @@ struct Integrator {
             w = mk2(fmaxf(fabsf(wA.x), fabsf(wB.x)), fmaxf(fabsf(wA.y), fabsf(wB.y))) * 4.0f;
             end_events();
         }
-        probe_err = ind2; probe_ep = fmaxf(fabsf(w.x), fabsf(w.y)); probe_ev = 0.0f;
+        probe_err = ind2; probe_ep = fmaxf(fabsf(w.x), fabsf(w.y));  // (diagnostics; probe_ev: 1 = one step, 2 = two halves)
 
         const bool crossing = ggmin <= 0.0f;
         probe = false;

@@ -100,7 +100,12 @@ def test_probe_step_stays_within_tolerance_and_scipy_build_follows_step_counts(e
             else:
                 kp = tw["path"] == 0  # a kept step: one step, never terminal, error indicator below the bound
                 assert (n_rk[kp] == 1).all() and not term[kp].any() and not (probe & ~kp).any()
-                assert tw["probe_abs"][kp].max() <= (1.5e-6 if o.is_goal else 1e-5) * 1.001
+                assert tw["probe_abs"][kp, 0].max() <= (1.5e-6 if o.is_goal else 1e-5) * 1.001
+                halves = kp & (tw["probe_abs"][:, 1] == 2)  # kept as two steps of half the length (fast passes close to a surface)
+                if k == 1:
+                    assert halves.sum() > 300 and (kp & (tw["probe_abs"][:, 1] == 1)).sum() > 3000
+                    rel = np.abs(tw["reward"] - ref["reward"]) / np.maximum(1, np.abs(ref["reward"]))
+                    assert rel[halves].max() <= 0.6 * TOL_REWARD_REL
             if k == 0:  # (the adversarial grazes are not held to scipy's step count by either build)
                 assert ((n_rk == nref) | probe).all()
                 if which == "probe":
