@@ -111,3 +111,50 @@ def test_no_vector_register_spills_in_the_default_kernels():
     assert not (set(spilled) - exempt), {n: spilled[n] for n in set(spilled) - exempt}
     pair = [r for r in rows if "goal_pair_rollout_kernel" in r["name"]]
     assert len(pair) == 12 and all(int(r["VGPRs"]) <= 256 and int(r["ScratchSize [bytes/lane]"]) == 0 for r in pair)
+
+
+def test_fast_step_coefficients_satisfy_the_order_conditions():
+    """The constants of Integrator::fast_step (sg_device.hpp, N5_*) are Nystrom's fifth-order method for x'' = f(t, x)
+    (Hairer, Norsett, Wanner I, II.14): read out of the header, they satisfy the order conditions up to order 5 -- the
+    quadrature conditions b.c^k = 1/(k+1), the row sums sum_j abar_ij = c_i^2/2, bbar_i = b_i (1 - c_i), and the three
+    conditions that involve the stage matrix (b.Abar c = 1/24, b.(c Abar c) = 1/30, b.Abar c^2 = 1/60) -- the indicator weights
+    D_j = abar_4j - bbar_j sum to zero (a constant force has no error), and a step of the method converges with order 5
+    (local error ratio 64 per halving) on a forced two-body problem."""
+    from fractions import Fraction as Fr
+    from conftest import ROOT
+    src = open(os.path.join(ROOT, "space_gym_amd", "csrc", "sg_device.hpp")).read()
+    vals = {}
+    for name, expr in re.findall(r"\b(N5_[A-Z0-9]+) = ([^,;]+)", src):
+        expr = expr.replace("(float)", "").replace("f", "").strip()
+        vals[name] = float(eval(re.sub(r"(\d+\.?\d*)", r"Fr('\1')", expr), {"Fr": Fr}))
+    c = np.array([0.0, vals["N5_C2"], vals["N5_C3"], 1.0])
+    A = np.zeros((4, 4))
+    A[1, 0] = vals["N5_A21"]; A[2, :2] = [vals["N5_A31"], vals["N5_A32"]]; A[3, :3] = [3 / 10, -2 / 35, 9 / 35]  # (row 4 enters as D)
+    b = np.array([vals["N5_B1"], vals["N5_B2"], vals["N5_B3"], vals["N5_B4"]])
+    bb = np.array([vals["N5_BB1"], vals["N5_BB2"], vals["N5_BB3"], 0.0])
+    D = np.array([vals["N5_D1"], vals["N5_D2"], vals["N5_D3"]])
+    tol = 1e-15
+    for k in range(5):
+        assert abs(b @ c ** k - 1 / (k + 1)) < tol
+    assert np.abs(bb - b * (1 - c)).max() < tol and np.abs(A.sum(1) - c ** 2 / 2).max() < tol
+    assert abs(b @ (A @ c) - 1 / 24) < tol and abs(b @ (c * (A @ c)) - 1 / 30) < tol and abs(b @ (A @ c ** 2) - 1 / 60) < tol
+    assert np.abs(D - (A[3, :3] - bb[:3])).max() < 1e-8 and abs(D.sum()) < 1e-7  # (D is rounded to float in the header)
+
+    def f(t, x):
+        r2 = x @ x
+        return -x / (r2 * np.sqrt(r2)) + 0.3 * np.array([np.cos(1 + 3 * t), np.sin(1 + 3 * t)])
+
+    def step(x, v, h):
+        k = []
+        for i in range(4):
+            k.append(f(c[i] * h, x + c[i] * h * v + h * h * sum(A[i, j] * k[j] for j in range(i))))
+        return x + h * v + h * h * sum(bb[j] * k[j] for j in range(4)), v + h * sum(b[j] * k[j] for j in range(4))
+
+    from scipy.integrate import solve_ivp
+    x0, v0 = np.array([1.0, 0.2]), np.array([0.1, 0.9])
+    err = []
+    for h in (0.2, 0.1, 0.05):
+        ref = solve_ivp(lambda t, y: np.r_[y[2:], f(t, y[:2])], (0, h), np.r_[x0, v0], method="DOP853", rtol=3e-14, atol=1e-16).y[:, -1]
+        x1, v1 = step(x0, v0, h)
+        err.append(max(np.abs(x1 - ref[:2]).max(), np.abs(v1 - ref[2:]).max()))
+    assert 50 < err[0] / err[1] < 80 and 50 < err[1] / err[2] < 80
