@@ -492,6 +492,8 @@ struct Integrator {
     // Vn = the velocity at its end, w = fourth stage position - end position (the error indicator).
     SG_MFN void nystrom5(float h, f2 P0, f2 V, f2 T, f2 Tp, f2 g1, f2 &rest, f2 &Vn, f2 &w) const {
         const float hh = h * h, hg = hh * gm;
+        // A = (1 - cos phi) / phi^2, B = (phi - sin phi) / phi^2 at phi = omega c h for the nodes c = 1/5, 2/3 (packed) and 1,
+        // S = sin phi / phi at the end: series in phi^2, |phi| <= 0.35 (truncation below 1e-7 relative)
         const float ph = om * h, z4 = ph * ph;
         const f2 ph23 = mk2(N5_C2, N5_C3) * ph, z23 = ph23 * ph23;
         const f2 A23 = fma2(z23, fma2(z23, 1.0f / 720, -1.0f / 24), 0.5f);
