@@ -53,9 +53,46 @@ typedef struct sg_config {
                                   (dynamic_model.py:138-141,160-161) and the angular-velocity event (:210-212) is live */
 } sg_config;
 
+/* The keyword arguments of the reference's constructors, GoalEnv.__init__ (gym_space/envs/goal.py:18-31) and
+ * KeplerEnv.__init__ (gym_space/envs/kepler.py:189-203), on top of what gym_space/__init__.py:26-146 registers for the id --
+ * what gym.make(id, **kwargs) does.  sg_params_init() sets every field to "keep the id's registered value" (NaN; the integers
+ * -1); set the ones to override.  ship_steering is sg_config.steering; fixed_position, reward_value and renderer_kwargs are
+ * read by nothing on the step path of the reference and have no field.  Keywords of the other family are refused, as Python
+ * refuses an unexpected keyword argument. */
+typedef struct sg_params {
+    uint32_t struct_size;          /* sizeof(sg_params), set by sg_params_init */
+    int32_t n_planets;             /* GoalEnv: 2, 3 or 4 (goal.py:25; 1 is a different sampler, :78-107, not served) */
+    int32_t randomize;             /* KeplerEnv: 0 / 1 (kepler.py:191,257-259: a new reference orbit every episode) */
+    int32_t reserved;
+    /* GoalEnv._reward, goal.py:147-158 */
+    double goal_vel_reward_scale;  /* goal.py:20,49 (x _distance_fctr = 100, :16,163) */
+    double safety_reward_scale;    /* goal.py:21,51 (x 100, :226) */
+    double goal_sparse_reward;     /* goal.py:22,50,155 */
+    double survival_reward_scale;  /* goal.py:25,48,150 */
+    double danger_zone;            /* goal.py:24,32,221: the safety term acts within this distance of the nearest planet's surface */
+    /* KeplerEnv._dense_reward5, kepler.py:111-150 */
+    double ref_orbit_a, ref_orbit_eccentricity, ref_orbit_angle; /* kepler.py:192-194 */
+    double numerator_C, rad_penalty_C, act_penalty_C;             /* kepler.py:196-198,138-150 */
+    double step_size;              /* kepler.py:199 (the constructor default is 0.1, every registered id passes 0.07); GoalEnv's is
+                                      fixed at 0.07 (goal.py:66).  Up to 0.072 the env-step is one Nystrom step with the thrust in
+                                      closed form; longer ones go through the Dormand-Prince kernels; refused where the heading
+                                      could advance by more than pi / 4 within one env-step (Steering.velocity: above 0.157) */
+    /* ShipParams (goal.py:45-47, kepler.py:207-209) */
+    double ship_moi;               /* moment of inertia (Steering.acceleration only: dynamic_model.py:160-161) */
+    double max_engine_force;       /* dynamic_model.py:171; 0 .. 4 */
+} sg_params;
+void sg_params_init(sg_params *params);
+
 /* GoalContinuousEnv(**kwargs) / KeplerContinuousEnv(**kwargs) construction (goal.py:18-72,
- * kepler.py:189-231) for num_envs instances on GPU `device`. */
+ * kepler.py:189-231) for num_envs instances on GPU `device`: sg_create with the kwargs the id was registered with
+ * (gym_space/__init__.py:26-146), sg_create_ex with `params` on top of them (NULL: none).
+ * num_envs is at most 4 194 304 per handle (the episode queue of the rollout kernels is addressed by 32-bit offsets); larger
+ * batches are several handles with disjoint env_index_base.  Besides its device columns (~100-490 B per env) a handle owns two
+ * page-locked result blocks for sg_step_begin / sg_step_end of (2 obs_dim + 1.5) * 4 B per env each. */
 int sg_create(const sg_config *cfg, int device, sg_env **out);
+int sg_create_ex(const sg_config *cfg, const sg_params *params, int device, sg_env **out);
+/* The parameters a handle was built with, every field filled in (the effective values). */
+int sg_get_params(const sg_env *env, sg_params *out);
 int sg_destroy(sg_env *env);
 /* The same for a batch of cfg->num_envs envs cut into contiguous blocks over n_devices GPUs (one handle per device, the
  * remainder spread over the first ones; env_index_base of block k = cfg->env_index_base + its first env): envs never
@@ -64,6 +101,7 @@ int sg_destroy(sg_env *env);
  * exchange a single-process VectorEnv view needs on top (a rooted gather of obs | reward | done per step) is
  * space_gym_amd/sharded.py's, over torch.distributed (RCCL). */
 int sg_create_sharded(const sg_config *cfg, int n_devices, const int *devices, sg_env **handles_out);
+int sg_create_sharded_ex(const sg_config *cfg, const sg_params *params, int n_devices, const int *devices, sg_env **handles_out);
 const char *sg_last_error(const sg_env *env); /* env may be NULL: last error of a failed sg_create */
 
 int64_t sg_num_envs(const sg_env *env);

@@ -67,14 +67,36 @@ def _p(a, t):
 class Oracle:
     """fp64 CPU restatement for one registered env id."""
 
-    def __init__(self, env_id, threads=1, steering_acceleration=False):
+    # constructor keywords of the reference (goal.py:18-31, kepler.py:189-203) -> field of sgo_params
+    KWARGS = dict(max_engine_force="max_engine_force", ship_moi="moi", danger_zone="danger_zone",
+                  survival_reward_scale="survival_reward_scale", goal_vel_reward_scale="goal_vel_reward_scale",
+                  safety_reward_scale="safety_reward_scale", goal_sparse_reward="goal_sparse_reward",
+                  ref_orbit_a="ref_orbit_a", ref_orbit_eccentricity="ref_orbit_eccentricity", ref_orbit_angle="ref_orbit_angle",
+                  numerator_C="numerator_C", rad_penalty_C="rad_penalty_C", act_penalty_C="act_penalty_C", step_size="step_size")
+
+    def __init__(self, env_id, threads=1, steering_acceleration=False, **kwargs):
+        """kwargs: keyword arguments of the reference's constructor on top of the id's registered ones (gym.make(id, **kwargs))"""
         self.lib = C.CDLL(build())
         self.env_id = env_id
         self.threads = int(threads)
         self.params = Params()
         self.lib.sgo_params_for_id.argtypes = [C.c_char_p, C.POINTER(Params)]
-        if self.lib.sgo_params_for_id(env_id.encode(), C.byref(self.params)) != 0:
-            raise ValueError(f"unknown env id {env_id!r}")
+        base_id = env_id
+        if "n_planets" in kwargs:  # GoalEnv(n_planets=k): the tiling, radii and masses of the k-planet ids (goal.py:83-87,43)
+            n = int(kwargs.pop("n_planets"))
+            base_id = f"GoalDiscrete{n}-v0" if "Discrete" in env_id else f"GoalContinuous{n}P-v0"
+        if self.lib.sgo_params_for_id(base_id.encode(), C.byref(self.params)) != 0:
+            raise ValueError(f"unknown env id {base_id!r}")
+        if base_id != env_id:  # what the id itself sets beyond the planet count (max_engine_force = 1 of the GoalDiscrete ids)
+            own = Params()
+            self.lib.sgo_params_for_id(env_id.encode(), C.byref(own))
+            self.params.max_engine_force = own.max_engine_force
+        if "ship_steering" in kwargs:
+            steering_acceleration = int(kwargs.pop("ship_steering")) == 0
+        if "randomize" in kwargs:
+            self.params.randomize_orbit = int(bool(kwargs.pop("randomize")))
+        for k, v in kwargs.items():
+            setattr(self.params, self.KWARGS[k], float(v))
         self.params.steering_acceleration = int(bool(steering_acceleration))  # Steering.acceleration (ship_steering=0)
         self.lib.sgo_obs_dim.argtypes = [C.POINTER(Params)]
         self.obs_dim = self.lib.sgo_obs_dim(C.byref(self.params))

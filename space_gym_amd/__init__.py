@@ -4,6 +4,6 @@ Host surface: `make_vec(env_id, num_envs)` -> SpaceGymVectorEnv (gym.vector.Vect
 hand-written HIP kernels behind the C ABI in include/spacegym.h.  There is no CPU implementation in this package.
 """
 from .registration import ENV_SPECS, register_with_gym  # noqa: F401
-from .vector_env import SpaceGymVectorEnv, StepInfo, make_vec  # noqa: F401
+from .vector_env import SpaceGymVectorEnv, StepInfo, make_vec, make_vec_from_class  # noqa: F401
 
-__all__ = ["make_vec", "SpaceGymVectorEnv", "StepInfo", "ENV_SPECS", "register_with_gym"]
+__all__ = ["make_vec", "make_vec_from_class", "SpaceGymVectorEnv", "StepInfo", "ENV_SPECS", "register_with_gym"]

@@ -15,6 +15,16 @@ class SgConfig(C.Structure):
                 ("steering", C.c_int32)]
 
 
+class SgParams(C.Structure):
+    """sg_params (include/spacegym.h): the reference's constructor kwargs; NaN / -1 keeps the id's registered value"""
+    _fields_ = [("struct_size", C.c_uint32), ("n_planets", C.c_int32), ("randomize", C.c_int32), ("reserved", C.c_int32),
+                ("goal_vel_reward_scale", C.c_double), ("safety_reward_scale", C.c_double), ("goal_sparse_reward", C.c_double),
+                ("survival_reward_scale", C.c_double), ("danger_zone", C.c_double),
+                ("ref_orbit_a", C.c_double), ("ref_orbit_eccentricity", C.c_double), ("ref_orbit_angle", C.c_double),
+                ("numerator_C", C.c_double), ("rad_penalty_C", C.c_double), ("act_penalty_C", C.c_double), ("step_size", C.c_double),
+                ("ship_moi", C.c_double), ("max_engine_force", C.c_double)]
+
+
 class SgTerminalList(C.Structure):
     _fields_ = [("count", C.c_void_p), ("step_env", C.c_void_p), ("obs", C.c_void_p), ("capacity", C.c_uint32)]
 
@@ -31,7 +41,11 @@ class NativeError(RuntimeError):
 _fp, _u8p, _i32p, _vp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_void_p
 SYMBOLS = {
     "sg_create": (C.c_int, [C.POINTER(SgConfig), C.c_int, C.POINTER(_vp)]),
+    "sg_create_ex": (C.c_int, [C.POINTER(SgConfig), C.POINTER(SgParams), C.c_int, C.POINTER(_vp)]),
+    "sg_params_init": (None, [C.POINTER(SgParams)]),
+    "sg_get_params": (C.c_int, [_vp, C.POINTER(SgParams)]),
     "sg_create_sharded": (C.c_int, [C.POINTER(SgConfig), C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "sg_create_sharded_ex": (C.c_int, [C.POINTER(SgConfig), C.POINTER(SgParams), C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
     "sg_destroy": (C.c_int, [_vp]),
     "sg_last_error": (C.c_char_p, [_vp]),
     "sg_num_envs": (C.c_int64, [_vp]),

@@ -848,6 +848,20 @@ struct Integrator {
         return status;
     }
 
+    // Only the step that is tried first (the fast step; Steering.acceleration: the probe step), for callers that hand every
+    // env-step it does not settle to somebody else (the one-launch-per-step kernels: lanes whose env-step is not a kept first
+    // step are compacted across the workgroup and replayed there by begin(use_probe = false) + run(), which is the same
+    // arithmetic as going on from here).  kRkFinished: kept, `o` is the result; kRkEventDeferred: the env-step is terminal
+    // (o.done = 1; the terminal state is on scipy's sequence); kRkContinue: scipy's sequence decides.  `sink` must return true.
+    template <typename SINK>
+    SG_MFN int first(StepResult &o, SINK &&sink) {
+        int status;
+        if (!ACCEL && fast) { fast = false; status = fast_step(o, sink); }
+        else status = attempt(o, sink);
+        if (status == kRkFinished) finish(o);
+        return status;
+    }
+
     // solve_ivp's event handling for an accepted step with sign changes (ivp.py:673-694): the earliest root over the
     // step's 4th-order dense output (rk.py:178-192) becomes the end of the env-step.  Needs set_constants() only.
     SG_MFN void solve_event(const EventCase &ev, StepResult &o) const {
@@ -1422,9 +1436,11 @@ SG_FN void translate_action(float &a0, float &a1, float max_engine_force, float 
 
 // omega at t = 0 and its rate for the env-step: Steering.velocity pins omega = 5 a1 (dynamic_model.py:138-141);
 // Steering.acceleration keeps the state's omega and applies alpha = (a1 * max_thruster_force) / moi (:160-161,175)
+// (the ACCEL kernels also serve Steering.velocity with an env-step too long for the fast step -- sg_host_config.hpp,
+//  needs_general_kernels -- as the special case alpha = 0, omega = the commanded one: hence the run-time test in them)
 template <bool ACCEL>
 SG_FN void steering(const SgDev &c, float a1, float om_cmd, float om_state, float &om0, float &alpha) {
-    if (ACCEL) { om0 = om_state; alpha = (a1 * c.max_thruster_force) * c.inv_moi; }
+    if (ACCEL && c.steering_acceleration) { om0 = om_state; alpha = (a1 * c.max_thruster_force) * c.inv_moi; }
     else { om0 = om_cmd; alpha = 0.0f; }
 }
 
@@ -1511,11 +1527,13 @@ SG_FN KeplerStepConsts kepler_step_consts(const SgDev &c) {
 struct StepConsts {
     float max_engine_force, h, half_world, gm, omega_limit, planet_r, max_thruster_force, inv_moi;
     double planet_r_d;
+    int32_t steering_acceleration;  // (read by the ACCEL kernels only: see steering())
 };
 SG_FN StepConsts step_consts(const SgDev &c) {
     StepConsts k;
     k.max_engine_force = c.max_engine_force; k.h = c.h; k.half_world = c.half_world; k.gm = c.gm; k.omega_limit = c.omega_limit;
     k.planet_r = c.planet_r; k.max_thruster_force = c.max_thruster_force; k.inv_moi = c.inv_moi; k.planet_r_d = c.planet_r_d;
+    k.steering_acceleration = c.steering_acceleration;
     return k;
 }
 template <int N, bool ACCEL = false>
@@ -1523,7 +1541,7 @@ SG_FN void goal_env_begin(const StepConsts &k, const GoalEnv<N> &e, float a0, fl
                           bool use_probe = true) {
     float engine, F, om, om0, alpha;
     translate_action(a0, a1, k.max_engine_force, engine, F, om);
-    if (ACCEL) { om0 = e.om; alpha = (a1 * k.max_thruster_force) * k.inv_moi; }  // steering<ACCEL>
+    if (ACCEL && k.steering_acceleration) { om0 = e.om; alpha = (a1 * k.max_thruster_force) * k.inv_moi; }  // steering<ACCEL>
     else { om0 = om; alpha = 0.0f; }
     float cR[N];
     double cRd[N];

@@ -115,6 +115,76 @@ inline int fill_config(const char *id, SgDev &d) {
     return -1;
 }
 
+// The constructor kwargs of the reference classes on top of an id's registered ones (sg_params, include/spacegym.h):
+// GoalEnv.__init__ goal.py:18-72, KeplerEnv.__init__ kepler.py:189-231; gym.make(id, **kwargs) overrides what
+// gym_space/__init__.py:26-146 registered the same way.  A field that is NaN (ints: negative) keeps the id's value.
+// Returns NULL, or what is wrong with the parameters.  P: any struct with sg_params' fields.
+template <typename P>
+inline const char *apply_params(const P &p, SgDev &d) {
+    auto given = [](double v) { return !std::isnan(v); };
+    const int discrete = d.discrete_actions, max_steps = d.max_episode_steps;
+    float engine = d.max_engine_force, inv_moi = d.inv_moi;
+    if (given(p.max_engine_force)) {
+        if (!(p.max_engine_force >= 0.0 && p.max_engine_force <= 4.0)) return "max_engine_force must be in [0, 4]";
+        engine = (float)p.max_engine_force;
+    }
+    if (given(p.ship_moi)) {
+        if (!(p.ship_moi > 0.0)) return "ship_moi must be positive";
+        inv_moi = (float)(1.0 / p.ship_moi);
+    }
+    if (d.family == SG_FAMILY_GOAL) {
+        if (given(p.ref_orbit_a) || given(p.ref_orbit_eccentricity) || given(p.ref_orbit_angle) || given(p.numerator_C) ||
+            given(p.rad_penalty_C) || given(p.act_penalty_C) || given(p.step_size) || p.randomize >= 0)
+            return "a KeplerEnv keyword (ref_orbit_*, *_C, step_size, randomize) for a Goal id: GoalEnv.__init__ has no such argument "
+                   "(its step_size is fixed at 0.07, goal.py:66)";
+        if (p.n_planets >= 0 && p.n_planets != d.n_planets) {
+            // (n_planets = 1 is another sampler in the reference, goal.py:78-107, used by no registered id: not served)
+            if (p.n_planets < 2 || p.n_planets > SG_MAX_PLANETS) return "n_planets must be 2, 3 or 4";
+            fill_goal(d, p.n_planets);
+        }
+        // GoalEnv._reward (goal.py:147-158) with the scales of the constructor (goal.py:48-51) and _distance_fctr = 100 (:16)
+        if (given(p.survival_reward_scale)) d.survival = p.survival_reward_scale;
+        if (given(p.goal_vel_reward_scale)) d.goal_scale = p.goal_vel_reward_scale * 100.0;
+        if (given(p.safety_reward_scale)) d.safety_scale = p.safety_reward_scale * 100.0;
+        if (given(p.goal_sparse_reward)) d.sparse = p.goal_sparse_reward;
+        if (given(p.danger_zone)) {  // goal.py:32,221
+            if (!(p.danger_zone >= 0.0)) return "danger_zone must not be negative";
+            d.danger_r2 = (d.planet_r_d + p.danger_zone) * (d.planet_r_d + p.danger_zone);
+        }
+    } else {
+        if (given(p.survival_reward_scale) || given(p.goal_vel_reward_scale) || given(p.safety_reward_scale) || given(p.goal_sparse_reward) ||
+            given(p.danger_zone) || p.n_planets >= 0)
+            return "a GoalEnv keyword (*_reward_scale, goal_sparse_reward, danger_zone, n_planets) for a Kepler id: KeplerEnv.__init__ "
+                   "has no such argument";
+        const double a = given(p.ref_orbit_a) ? p.ref_orbit_a : d.k_a, ecc = given(p.ref_orbit_eccentricity) ? p.ref_orbit_eccentricity : d.k_ecc;
+        const double phi = given(p.ref_orbit_angle) ? p.ref_orbit_angle : d.k_phi;
+        if (!(a > 0.0)) return "ref_orbit_a must be positive";
+        if (!(ecc >= 0.0 && ecc < 1.0)) return "ref_orbit_eccentricity must be in [0, 1)";
+        const double C = given(p.numerator_C) ? p.numerator_C : d.k_C, Cr = given(p.rad_penalty_C) ? p.rad_penalty_C : d.k_Cr;
+        const float Ca = given(p.act_penalty_C) ? (float)p.act_penalty_C : d.k_Ca, h = given(p.step_size) ? (float)p.step_size : d.h;
+        if (!(h > 0.0f)) return "step_size must be positive";
+        const int rnd = p.randomize >= 0 ? (p.randomize ? 1 : 0) : d.randomize_orbit;
+        fill_kepler(d, a, ecc, phi, rnd);  // (derives b, c, cos / sin of the angle: kepler.py:43-58)
+        d.k_C = C; d.k_Cr = Cr; d.k_Ca = Ca; d.h = h;
+    }
+    d.discrete_actions = discrete; d.max_episode_steps = max_steps;
+    d.max_engine_force = engine; d.inv_moi = inv_moi;
+    return nullptr;
+}
+
+// Which integrator serves a parameter block.  The fast step's closed-form thrust integrals (sg_device.hpp, Integrator::fast_step)
+// are series for a heading advance of at most 0.36 rad per env-step: |omega| = 5 |a1| <= 5 with Steering.velocity, so
+// step_size <= 0.072 -- every registered id (0.07).  A longer env-step (KeplerEnv's constructor default is 0.1, kepler.py:197) is
+// integrated by the kernels written for Steering.acceleration (one Dormand-Prince step tried first, heading by sincos_poly),
+// which serve Steering.velocity as the special case alpha = 0, omega = 5 a1.  Their heading advance within an env-step is at most
+// omega_limit * h + alpha_max h^2 / 2 and must stay within sincos_poly's pi / 4.
+inline bool needs_general_kernels(const SgDev &d) { return d.steering_acceleration || !(5.0f * d.h <= 0.36f); }
+inline bool step_size_supported(const SgDev &d) {
+    const double alpha_max = (double)d.max_thruster_force * d.inv_moi, h = d.h;
+    const double adv = d.steering_acceleration ? d.omega_limit * h + 0.5 * alpha_max * h * h : 5.0 * h;
+    return adv <= 0.785;
+}
+
 inline int obs_dim(const SgDev &d) { return d.family == SG_FAMILY_GOAL ? 7 + 2 * d.n_planets + 2 : 10; }
 
 }  // namespace sg

@@ -33,15 +33,54 @@ ENV_SPECS = {
 }
 
 
-def obs_dim(env_id):
+# Constructor signatures of the reference classes: keyword -> default (REQUIRED: no default).  GoalEnv.__init__ goal.py:18-31,
+# KeplerEnv.__init__ kepler.py:189-203.  `fixed_position`, `reward_value` and `renderer_kwargs` are accepted and ignored: nothing
+# on the reference's step path reads them.
+REQUIRED = object()
+CLASS_KWARGS = {
+    "goal": dict(goal_vel_reward_scale=REQUIRED, safety_reward_scale=REQUIRED, goal_sparse_reward=REQUIRED, fixed_position=False,
+                 danger_zone=0.25, survival_reward_scale=0.0, n_planets=2, ship_steering=0, ship_moi=0.01, max_engine_force=0.4,
+                 renderer_kwargs=None),
+    "kepler": dict(randomize=False, ref_orbit_a=1.2, ref_orbit_eccentricity=0.5, ref_orbit_angle=3.75, reward_value=0,
+                   numerator_C=0.01, rad_penalty_C=2.0, act_penalty_C=0.5, step_size=0.1, ship_steering=0, ship_moi=0.01,
+                   max_engine_force=0.4),
+}
+# The reference's classes (gym_space/envs/goal.py:286-291, kepler.py:270-275), for make_vec_from_class: the id whose family and
+# action space they share; every keyword then comes from the class defaults above and the caller.
+ENV_CLASSES = {"GoalContinuousEnv": "GoalContinuous2P-v0", "GoalDiscreteEnv": "GoalDiscrete2-v0",
+               "KeplerContinuousEnv": "KeplerCircleOrbit-v0", "KeplerDiscreteEnv": "KeplerDiscrete-v0"}
+_IGNORED = ("fixed_position", "reward_value", "renderer_kwargs")
+
+
+def constructor_kwargs(env_id, overrides=None, from_class=False):
+    """The keyword arguments the reference would construct the env with: the class defaults, the kwargs the id was registered
+    with (gym_space/__init__.py:26-146; not with from_class) and the caller's overrides, as gym.make(id, **overrides) merges
+    them.  An unknown keyword or a missing required one raises TypeError like the reference's constructor."""
+    fam = ENV_SPECS[env_id]["family"]
+    kw = dict(CLASS_KWARGS[fam])
+    if not from_class:
+        kw.update(ENV_SPECS[env_id]["kwargs"])
+    for k, v in (overrides or {}).items():
+        if k not in CLASS_KWARGS[fam]:
+            raise TypeError(f"__init__() got an unexpected keyword argument {k!r} ({'GoalEnv' if fam == 'goal' else 'KeplerEnv'})")
+        kw[k] = v
+    missing = [k for k, v in kw.items() if v is REQUIRED]
+    if missing:
+        raise TypeError(f"__init__() missing required arguments: {missing}")
+    if fam == "goal" and kw.get("fixed_position"):
+        raise ValueError("fixed_position=True is not served (the reference never reads it either: goal.py:23)")
+    return kw
+
+
+def obs_dim(env_id, n_planets=None):
     s = ENV_SPECS[env_id]
-    return 7 + 2 * s["n_planets"] + 2 if s["family"] == "goal" else 10
+    return 7 + 2 * (n_planets or s["n_planets"]) + 2 if s["family"] == "goal" else 10
 
 
-def single_observation_space(env_id):
+def single_observation_space(env_id, n_planets=None):
     s = ENV_SPECS[env_id]
     if s["family"] == "goal":  # spaceship_env.py:102-111
-        high = [1.0, 1.0, 1.0, 1.0, np.inf, np.inf, 1.0] + (2 * s["n_planets"] + 2) * [2 * np.sqrt(2)]
+        high = [1.0, 1.0, 1.0, 1.0, np.inf, np.inf, 1.0] + (2 * (n_planets or s["n_planets"]) + 2) * [2 * np.sqrt(2)]
     else:  # kepler.py:158-170 (low = -high including the three orbit slots)
         high = [1.0, 1.0, 1.0, 1.0, np.inf, np.inf, 1.0, 2 * np.pi, 0.7, 2]
     high = np.array(high, dtype=np.float32)

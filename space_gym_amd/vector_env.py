@@ -19,7 +19,8 @@ import ctypes as C
 import numpy as np
 
 from . import _native
-from .registration import ENV_SPECS, is_discrete, obs_dim, single_action_space, single_observation_space
+from .registration import (ENV_CLASSES, ENV_SPECS, constructor_kwargs, is_discrete, obs_dim, single_action_space,
+                           single_observation_space)
 from .spaces import MultiDiscrete, batch_box
 
 
@@ -32,9 +33,13 @@ class SpaceGymVectorEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, env_id, num_envs, device=0, seed=0, env_index_base=0, max_episode_steps=None, auto_reset=True,
-                 validate_actions=True, terminal_observation=True, copy=True, steering="velocity"):
+                 validate_actions=True, terminal_observation=True, copy=True, steering=None, env_kwargs=None, from_class=False):
         """steering: "velocity" (ship_steering=1, what every registered id uses) or "acceleration" (ship_steering=0, the
-        constructor default of the reference classes: omega is a state, the thruster a torque).
+        constructor default of the reference classes: omega is a state, the thruster a torque); None: what env_kwargs say.
+        env_kwargs: keyword arguments of the reference's constructor (GoalEnv.__init__ goal.py:18-31, KeplerEnv.__init__
+        kepler.py:189-203) on top of the ones the id is registered with -- what gym.make(env_id, **env_kwargs) does; make_vec
+        passes its unknown keywords here.  from_class: the id only names the family and action space, every keyword comes from
+        the class defaults and env_kwargs (make_vec_from_class).
         validate_actions: step() checks on the host that the actions are in range, as the reference's step asserts
         (spaceship_env.py:71; discrete ids: ValueError, :201-202); off, out-of-range actions are clamped on the device (the
         device-tensor calls never validate: that would need a device-to-host synchronisation).
@@ -44,10 +49,20 @@ class SpaceGymVectorEnv:
             raise ValueError(f"unknown env id {env_id!r}; served ids: {sorted(ENV_SPECS)}")
         self._lib = _native.load()
         self.env_id, self.num_envs, self.device = env_id, int(num_envs), int(device)
-        self.spec = ENV_SPECS[env_id]
-        self.obs_dim = obs_dim(env_id)
+        self.spec = dict(ENV_SPECS[env_id])
+        # the constructor's keyword arguments as the reference would see them, and the native parameter block they fill
+        self.env_kwargs = constructor_kwargs(env_id, env_kwargs, from_class=from_class)
+        if steering is None:
+            if self.env_kwargs["ship_steering"] not in (0, 1):  # Steering.angle: no thruster does anything (dynamic_model.py:138-141,160-163)
+                raise ValueError("ship_steering must be 0 (Steering.acceleration) or 1 (Steering.velocity)")
+            steering = "velocity" if self.env_kwargs["ship_steering"] == 1 else "acceleration"
+        self.env_kwargs["ship_steering"] = {"velocity": 1, "acceleration": 0}[steering]
+        params = self._native_params(self.env_kwargs)
+        if self.spec["family"] == "goal":
+            self.spec["n_planets"] = int(self.env_kwargs["n_planets"])
+        self.obs_dim = obs_dim(env_id, self.spec["n_planets"])
         self.n_planets = self.spec["n_planets"]
-        self.single_observation_space = single_observation_space(env_id)
+        self.single_observation_space = single_observation_space(env_id, self.n_planets)
         self.single_action_space = single_action_space(env_id)
         self.observation_space = batch_box(self.single_observation_space, self.num_envs)
         self.discrete = is_discrete(env_id)
@@ -59,8 +74,8 @@ class SpaceGymVectorEnv:
                                env_index_base=int(env_index_base), max_episode_steps=int(max_episode_steps or 0),
                                auto_reset=int(bool(auto_reset)), steering={"velocity": 0, "acceleration": 1}[steering])
         h = C.c_void_p()
-        rc = self._lib.sg_create(C.byref(cfg), self.device, C.byref(h))
-        _native.check(self._lib, None, rc, "sg_create")
+        rc = self._lib.sg_create_ex(C.byref(cfg), C.byref(params), self.device, C.byref(h))
+        _native.check(self._lib, None, rc, "sg_create_ex")
         self._h = h
         assert self._lib.sg_obs_dim(h) == self.obs_dim
         B, D = self.num_envs, self.obs_dim
@@ -71,6 +86,28 @@ class SpaceGymVectorEnv:
         self._pending = False
         self._blocks = {}
         self._torch_bufs = None
+
+    def _native_params(self, kw):
+        """sg_params (include/spacegym.h) from the constructor's keyword arguments"""
+        p = _native.SgParams()
+        self._lib.sg_params_init(C.byref(p))
+        names = (("goal_vel_reward_scale", "safety_reward_scale", "goal_sparse_reward", "survival_reward_scale", "danger_zone")
+                 if self.spec["family"] == "goal" else
+                 ("ref_orbit_a", "ref_orbit_eccentricity", "ref_orbit_angle", "numerator_C", "rad_penalty_C", "act_penalty_C", "step_size"))
+        for k in names + ("ship_moi", "max_engine_force"):
+            setattr(p, k, float(kw[k]))
+        if self.spec["family"] == "goal":
+            p.n_planets = int(kw["n_planets"])
+        else:
+            p.randomize = int(bool(kw["randomize"]))
+        return p
+
+    def native_params(self):
+        """the parameters the handle was built with (sg_get_params), as a dict of the reference's keyword names"""
+        p = _native.SgParams()
+        self._ck(self._lib.sg_get_params(self._h, C.byref(p)), "sg_get_params")
+        out = {k: getattr(p, k) for k, _ in p._fields_ if k not in ("struct_size", "reserved")}
+        return {k: v for k, v in out.items() if not (isinstance(v, float) and np.isnan(v)) and v != -1}
 
     def _host_array(self, shape, dtype):
         """NumPy array over page-locked memory (sg_host_alloc); ordinary memory if pinning fails."""
@@ -410,6 +447,29 @@ class SpaceGymVectorEnv:
         return n.value, tot.value, mn.value, mx.value
 
 
+_ENGINE_KWARGS = ("device", "seed", "env_index_base", "max_episode_steps", "auto_reset", "validate_actions", "terminal_observation",
+                  "copy", "steering", "env_kwargs", "from_class")
+
+
 def make_vec(env_id, num_envs=1, **kwargs):
-    """Batched counterpart of gym.make(env_id) for the ids in gym_space/__init__.py."""
-    return SpaceGymVectorEnv(env_id, num_envs, **kwargs)
+    """Batched counterpart of gym.make(env_id, **kwargs) for the ids in gym_space/__init__.py: keywords of the reference's
+    constructors (GoalEnv.__init__ goal.py:18-31: goal_vel_reward_scale, safety_reward_scale, goal_sparse_reward, danger_zone,
+    survival_reward_scale, n_planets, ship_steering, ship_moi, max_engine_force; KeplerEnv.__init__ kepler.py:189-203: randomize,
+    ref_orbit_a, ref_orbit_eccentricity, ref_orbit_angle, numerator_C, rad_penalty_C, act_penalty_C, step_size, ship_steering,
+    ship_moi, max_engine_force) override what the id is registered with; the engine's own keywords (device, seed, ...) are
+    SpaceGymVectorEnv's."""
+    engine = {k: kwargs.pop(k) for k in list(kwargs) if k in _ENGINE_KWARGS}
+    if kwargs:
+        engine["env_kwargs"] = {**(engine.get("env_kwargs") or {}), **kwargs}
+    return SpaceGymVectorEnv(env_id, num_envs, **engine)
+
+
+def make_vec_from_class(class_name, num_envs=1, **kwargs):
+    """Batched counterpart of constructing one of the reference's classes directly -- GoalContinuousEnv(**kwargs),
+    GoalDiscreteEnv, KeplerContinuousEnv, KeplerDiscreteEnv (goal.py:286-291, kepler.py:270-275): the constructor's own
+    defaults apply (ship_steering=0, i.e. Steering.acceleration; KeplerEnv: step_size=0.1) and GoalEnv's three reward scales
+    are required.  No TimeLimit unless max_episode_steps is given (the classes have none; it is gym.make that adds it)."""
+    if class_name not in ENV_CLASSES:
+        raise ValueError(f"unknown class {class_name!r}; served: {sorted(ENV_CLASSES)}")
+    kwargs.setdefault("max_episode_steps", 2 ** 31 - 1)
+    return make_vec(ENV_CLASSES[class_name], num_envs, from_class=True, **kwargs)

@@ -633,3 +633,52 @@ def test_bench_line_contract():
     c = b["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s"
     assert c["single_core"]["cores"] == 1 and 0 < c["single_core"]["value"] <= c["value"] * 1.5
+
+
+@pytest.mark.parametrize("name", ["goal_a", "goal_b", "goal_c", "kepler_a", "kepler_b", "kepler_c", "kepler_d"])
+def test_constructor_kwargs_match_reference_golden(name):
+    """sg_create_ex / make_vec(env_id, **kwargs): the reference's constructor kwargs (goal.py:18-31, kepler.py:189-203) beyond
+    what the ids register -- fixtures from the unmodified reference (tools/gen_golden.py --stage kwargs); the env-steps of 0.1
+    (KeplerEnv's own default) go through the Dormand-Prince kernels, those up to 0.072 through the fast step."""
+    import json
+    from conftest import load_golden
+    import space_gym_amd as sg
+    d = load_golden("step_kw_" + name)
+    kw = json.loads(str(d["kwargs_json"]))
+    m = len(d["state0"])
+    env = sg.make_vec(str(d["env_id"]), m, device=0, seed=1, auto_reset=False, from_class=True, **kw)
+    p = env.native_params()
+    for k, v in kw.items():  # the handle holds what was asked for
+        if k in p:
+            assert abs(p[k] - float(v)) < 1e-6 * max(1.0, abs(float(v))), (k, p[k], v)
+    assert abs(p["step_size"] - float(d["const_step_size"])) < 1e-7
+    env.reset()
+    is_goal = "planets" in d
+    assert env.obs_dim == d["obs"].shape[1] and env.n_planets == (int(d["const_n_planets"]) if is_goal else 0)
+    env.set_state(ship=d["state0"], planets=d["planets"] if is_goal else None, goal=d["goal"] if is_goal else None,
+                  elapsed=np.zeros(m, np.int32))
+    obs, rew, done, info = env.step(d["action"])
+    st = env.get_state()
+    check_against(obs, rew, done, st["ship"], d["state1"], d["obs"], d["reward"], d["done"])
+    if is_goal:
+        changed = np.any(st["goal"] != d["goal"].astype(np.float32), axis=1)
+        assert np.array_equal(changed, d["goal_changed"].astype(bool))
+    env.close()
+    # the same parameters through K-step rollouts (wave-pair kernels) against one-launch-per-step: bit-identical
+    import torch
+    n, K = 4096, 24
+    envs = [sg.make_vec(str(d["env_id"]), n, device=0, seed=3, from_class=True, max_episode_steps=40, **kw) for _ in range(2)]
+    a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 2 - 1
+    outs = []
+    for k, e in enumerate(envs):
+        e.reset_torch()
+        e.set_unfused_rollout(k == 1)
+        o = torch.empty((K, n, e.obs_dim), device="cuda"); r = torch.empty((K, n), device="cuda")
+        dn = torch.empty((K, n), dtype=torch.uint8, device="cuda"); tr = torch.empty_like(dn)
+        e.rollout_torch(a, o, r, dn, tr)
+        e.check_status()
+        outs.append((o.cpu().numpy(), r.cpu().numpy(), dn.cpu().numpy(), tr.cpu().numpy()))
+        e.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    assert outs[0][2].sum() > 0

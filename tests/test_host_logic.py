@@ -158,3 +158,42 @@ def test_fast_step_coefficients_satisfy_the_order_conditions():
         x1, v1 = step(x0, v0, h)
         err.append(max(np.abs(x1 - ref[:2]).max(), np.abs(v1 - ref[2:]).max()))
     assert 50 < err[0] / err[1] < 80 and 50 < err[1] / err[2] < 80
+
+
+def test_constructor_kwargs_merge_like_gym_make():
+    """make_vec(env_id, **kwargs) merges the reference's constructor kwargs like gym.make(id, **kwargs): class defaults
+    (goal.py:18-31, kepler.py:189-203) < registered kwargs (gym_space/__init__.py:26-146) < the caller's; an unknown keyword or a
+    missing required one is a TypeError like the reference constructor's."""
+    import pytest
+    from space_gym_amd.registration import constructor_kwargs
+    kw = constructor_kwargs("GoalContinuous3P-v0")
+    assert kw["n_planets"] == 3 and kw["ship_steering"] == 1 and kw["danger_zone"] == 0.25 and kw["survival_reward_scale"] == 0.2
+    kw = constructor_kwargs("GoalContinuous3P-v0", dict(max_engine_force=0.7, danger_zone=0.4))
+    assert kw["max_engine_force"] == 0.7 and kw["danger_zone"] == 0.4 and kw["goal_vel_reward_scale"] == 5.0
+    kw = constructor_kwargs("KeplerCircleOrbit-v0")
+    assert kw["step_size"] == 0.07 and kw["ref_orbit_eccentricity"] == 0 and kw["ship_steering"] == 1
+    kw = constructor_kwargs("KeplerCircleOrbit-v0", from_class=True)  # KeplerContinuousEnv(): the class's own defaults
+    assert kw["step_size"] == 0.1 and kw["ref_orbit_eccentricity"] == 0.5 and kw["ship_steering"] == 0 and kw["ref_orbit_angle"] == 3.75
+    with pytest.raises(TypeError):
+        constructor_kwargs("GoalContinuous3P-v0", dict(step_size=0.1))  # GoalEnv.__init__ has no step_size (fixed: goal.py:66)
+    with pytest.raises(TypeError):
+        constructor_kwargs("KeplerCircleOrbit-v0", dict(danger_zone=0.1))
+    with pytest.raises(TypeError):
+        constructor_kwargs("GoalContinuous2P-v0", from_class=True)  # the three reward scales have no default
+
+
+def test_sg_params_layout_matches_the_header():
+    """the ctypes mirror of sg_params has the fields of include/spacegym.h in the same order"""
+    import re
+    from space_gym_amd import _native
+    header = open(os.path.join(ROOT, "include", "spacegym.h")).read()
+    body = header[header.index("typedef struct sg_params {"):header.index("} sg_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct sg_params {", "").strip()
+        if not decl:
+            continue
+        ctype, rest = decl.split(None, 1)
+        names += [n.strip() for n in rest.split(",")]
+    assert names == [f for f, _ in _native.SgParams._fields_], names

@@ -115,3 +115,33 @@ def test_vector_field_matches_reference():
     assert np.abs(f - d["goal3p_field"]).max() < 1e-13
     f = Oracle("KeplerEllipseEasy-v0").vector_field(d["kepler_easy_state"], d["kepler_easy_action"])
     assert np.abs(f - d["kepler_easy_field"]).max() < 1e-13
+
+
+KW_SETS = ["goal_a", "goal_b", "goal_c", "kepler_a", "kepler_b", "kepler_c", "kepler_d"]
+
+
+def load_kw_fixture(name):
+    """(fixture, base id, kwargs the reference was constructed with, constructed from the class?)"""
+    import json
+    from conftest import load_golden
+    d = load_golden("step_kw_" + name)
+    return d, str(d["env_id"]), json.loads(str(d["kwargs_json"])), True
+
+
+@pytest.mark.parametrize("name", KW_SETS)
+def test_oracle_matches_reference_constructor_kwargs(name):
+    """Parameter sets no id is registered with (GoalEnv.__init__ goal.py:18-31, KeplerEnv.__init__ kepler.py:189-203), captured
+    from the unmodified reference (tools/gen_golden.py --stage kwargs): reward scales, danger zone, engine force, moment of
+    inertia, planet count, reference orbit, reward constants, step sizes 0.05 / 0.1, both steerings."""
+    from space_gym_amd.registration import constructor_kwargs
+    d, base_id, kw, from_class = load_kw_fixture(name)
+    full = constructor_kwargs(base_id, kw, from_class=from_class)  # class defaults + the fixture's kwargs
+    full = {k: v for k, v in full.items() if k not in ("fixed_position", "reward_value", "renderer_kwargs")}
+    o = Oracle(base_id, **full)
+    assert abs(o.params.step_size - float(d["const_step_size"])) < 1e-15 and o.params.n_planets == int(d["const_n_planets"])
+    r = o.step(d["state0"], d["action"], d.get("planets"), d.get("goal"), with_diag=True)
+    assert np.array_equal(r["done"], d["done"]) and np.array_equal(r["goal_hit"], d["goal_changed"])
+    assert np.array_equal(r["diag"]["n_rk_steps"], d["n_rk_steps"]) and np.array_equal(r["diag"]["event_index"], d["event_index"])
+    assert np.abs(r["state1"] - d["state1"]).max() <= TOL_STATE and np.abs(r["obs"] - d["obs"]).max() <= TOL_OBS
+    assert np.abs(r["reward"] - d["reward"]).max() <= TOL_REWARD
+    assert (d["done"] == 1).sum() >= 100 and (d["done"] == 0).sum() >= 300

@@ -570,6 +570,61 @@ def stage_acceleration(args):
               f"({int((arrs['event_index'] == n_ev).sum())} by the angular-velocity event) -> {path}", flush=True)
 
 
+# Constructor kwargs beyond the registered ones (GoalEnv.__init__ goal.py:18-31, KeplerEnv.__init__ kepler.py:189-203): what
+# sg_params / make_vec(env_id, **kwargs) must reproduce.  (class, base id for the engine, kwargs)
+KWARGS_SETS = {
+    "goal_a": ("GoalContinuousEnv", "GoalContinuous3P-v0",
+               dict(n_planets=3, ship_steering=1, ship_moi=0.01, max_engine_force=0.7, goal_vel_reward_scale=3.0,
+                    safety_reward_scale=4.0, goal_sparse_reward=2.5, survival_reward_scale=0.05, danger_zone=0.4)),
+    "goal_b": ("GoalContinuousEnv", "GoalContinuous2P-v0",
+               dict(n_planets=2, ship_steering=1, ship_moi=0.01, max_engine_force=0.25, goal_vel_reward_scale=8.0,
+                    safety_reward_scale=20.0, goal_sparse_reward=10.0, survival_reward_scale=0.0, danger_zone=0.1)),
+    "goal_c": ("GoalContinuousEnv", "GoalContinuous2P-v0",  # another planet count than the base id's, Steering.acceleration, another moi
+               dict(n_planets=4, ship_steering=0, ship_moi=0.02, max_engine_force=0.55, goal_vel_reward_scale=5.0,
+                    safety_reward_scale=10.0, goal_sparse_reward=5.0, survival_reward_scale=0.2)),
+    "kepler_a": ("KeplerContinuousEnv", "KeplerCircleOrbit-v0",  # the constructor's own step size
+                 dict(ref_orbit_a=1.5, ref_orbit_eccentricity=0.3, ref_orbit_angle=2.0, step_size=0.1, ship_steering=1,
+                      numerator_C=0.02, rad_penalty_C=1.0, act_penalty_C=0.25, max_engine_force=0.4)),
+    "kepler_b": ("KeplerContinuousEnv", "KeplerEllipseEasy-v0",
+                 dict(ref_orbit_a=0.9, ref_orbit_eccentricity=0.6, ref_orbit_angle=5.0, step_size=0.07, ship_steering=1,
+                      numerator_C=0.05, rad_penalty_C=3.0, act_penalty_C=1.0, max_engine_force=0.7)),
+    "kepler_c": ("KeplerContinuousEnv", "KeplerCircleOrbit-v0",  # every class default (Steering.acceleration, step 0.1, a 1.2, e 0.5, angle 3.75) but the moi
+                 dict(ship_moi=0.02)),
+    "kepler_d": ("KeplerContinuousEnv", "KeplerEllipseHard-v0",  # a shorter env-step than the registered one
+                 dict(step_size=0.05, ship_steering=1, ref_orbit_a=1.1, ref_orbit_eccentricity=0.2, ref_orbit_angle=1.0)),
+}
+
+
+def stage_kwargs(args):
+    """Non-registered parameter sets, constructed like gym.make(id, **kwargs) / the classes themselves would."""
+    import json
+    registry, envs, dynamic_model = load_env_layer()
+    rec = IvpRecorder(dynamic_model)
+    for name, (cls_name, base_id, kwargs) in KWARGS_SETS.items():
+        rng = np.random.RandomState(sum(map(ord, name)) * 7919 % (1 << 31))
+        with contextlib.redirect_stdout(io.StringIO()):
+            env = getattr(envs, cls_name)(**kwargs)
+        rows = rollout_rows(env, rec, rng, args.rollout_steps // 3, args.keep_nonterminal // 3)
+        rows += (forced_goal_rows if is_goal(env) else forced_kepler_rows)(env, rec, rng, args.forced_each // 3)
+        if env.ship_params.steering.value == 0:  # angular-velocity event: |omega| close to the limit
+            for _ in range(args.forced_each):
+                env.reset(); quantise_env(env)
+                sv = env._ship_state._state_vec.copy()
+                sv[5] = rng.choice([-1.0, 1.0]) * (6.0 - rng.uniform(0.0, 0.5))
+                inject(env, q32(sv))
+                row, _ = step_and_record(env, rec, rng.uniform(-1, 1, size=2).astype(np.float32), KINDS.index("extreme_action"))
+                rows.append(row)
+        arrs = rows_to_arrays(rows, is_goal(env))
+        arrs.update(env_constants(env))
+        arrs["const_moi"] = np.asarray(env.ship_params.moi)
+        arrs["kind_names"] = np.array(KINDS)
+        arrs["env_id"] = np.array(base_id); arrs["class_name"] = np.array(cls_name); arrs["kwargs_json"] = np.array(json.dumps(kwargs))
+        path = os.path.join(OUT, f"step_kw_{name}.npz")
+        np.savez_compressed(path, **arrs)
+        print(f"kw_{name}: {len(rows)} transitions, {int(arrs['done'].sum())} terminal, {int(arrs['goal_changed'].sum())} goal hits, "
+              f"step_size {env.step_size} -> {path}", flush=True)
+
+
 def stage_vector_field(args):
     """SpaceshipEnv.vector_field(raw_action, state_vec) (spaceship_env.py:96-100): the RHS of the ODE, for model-based users."""
     registry, envs, _ = load_env_layer()
@@ -635,14 +690,14 @@ def stage_core(_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete", "random_orbits", "acceleration", "vector_field"], default="all")
+    ap.add_argument("--stage", choices=["all", "env", "core", "reset", "discrete", "random_orbits", "acceleration", "vector_field", "kwargs"], default="all")
     ap.add_argument("--rollout-steps", type=int, default=20000)
     ap.add_argument("--keep-nonterminal", type=int, default=1200)
     ap.add_argument("--forced-each", type=int, default=80)
     ap.add_argument("--n-resets", type=int, default=100000)
     args = ap.parse_args()
     if args.stage == "all":
-        for st in ("env", "core", "reset", "discrete", "random_orbits", "acceleration", "vector_field"):
+        for st in ("env", "core", "reset", "discrete", "random_orbits", "acceleration", "vector_field", "kwargs"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--stage", st,
                                    "--rollout-steps", str(args.rollout_steps),
                                    "--keep-nonterminal", str(args.keep_nonterminal),
@@ -659,6 +714,8 @@ def main():
         stage_acceleration(args)
     elif args.stage == "vector_field":
         stage_vector_field(args)
+    elif args.stage == "kwargs":
+        stage_kwargs(args)
     else:
         stage_core(args)
 
