@@ -107,6 +107,9 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # RCCL's intra-node transport shares device buffers between the ranks' processes; this pool's host driver only supports
+    # dmabuf IPC handles, and with the legacy mode RCCL's set-up fails with `hipIpcGetMemHandle: invalid argument` (the image
+    # exports the variable already; kept for a shell that does not)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.run(cmd, env=env).returncode
@@ -123,8 +126,8 @@ def main():
     ap.add_argument("--action-ring", type=int, default=0, help="distinct pre-generated action blocks (0: one per step)")
     ap.add_argument("--action-source", choices=["torch", "engine"], default="torch",
                     help="who draws the U(-1,1) action tape: torch.rand (per-rank generator) or sg_random_actions_device")
-    ap.add_argument("--repeats", type=int, default=5, help="the timed K-step region is run this many times; `value` is the first, "
-                    "the others are reported as ms_per_step_repeats / ms_per_step_median")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed K-step region is run this many times (SURVEY 8d); `value` is "
+                    "the median region, every region is in ms_per_step_repeats, the first one also as value_first_region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline sample")
     ap.add_argument("--preroll", type=int, default=12000,
                     help="untimed steps run before the warm-up steps, as part of the set-up: ~40 ms of the same kernel, so that "
@@ -235,7 +238,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     env.check_status()  # a rollout whose wave hand-off timed out is not a measurement
-    # ---- the same K-step region repeated (SURVEY 8d asks for >= 5 repeats and their median); `value` stays the first one
+    # ---- the same K-step region repeated (SURVEY 8d asks for >= 5 repeats and their median: that is `value`)
     repeats = [dt]
     for _ in range(max(0, args.repeats - 1)):
         sync_all()
@@ -261,6 +264,32 @@ def main():
         launches, kern_ms, kmin, kmax = env.get_profile()
         env.set_profiling(False)
     env.check_status()
+
+    # ---- the same K-step launch returning what the reference's step() returns with done=True as well: the LAST observation of
+    # every episode that ends (spaceship_env.py:75-78; sg_rollout_device_terminal, one record per finished env-step).  Extra keys,
+    # never `value`.
+    tobs_ms = tobs_kernel_us = tobs_records = None
+    if world == 1 and min(K, chunk) == K:
+        cap = int(B * K * 0.05) + 4096
+        tl = env.terminal_list_torch(cap)
+        for _ in range(2):
+            env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K], terminal=tl)
+        sync_all()
+        tt = time.perf_counter()
+        for _ in range(max(1, args.repeats)):
+            env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K], terminal=tl)
+        sync_all()
+        tobs_ms = (time.perf_counter() - tt) * 1e3 / max(1, args.repeats)
+        if timing:
+            env.set_profiling(True)
+            for _ in range(max(1, args.repeats)):
+                env.rollout_torch(act_seq[:K], obs[:K], rew[:K], done[:K], trunc[:K], terminal=tl)
+            sync_all()
+            n_l, t_ms, _, _ = env.get_profile()
+            env.set_profiling(False)
+            tobs_kernel_us = t_ms * 1e3 / max(1, n_l)
+        tobs_records = int(tl["count"].item())
+        env.check_status()
 
     # ---- A/B: the same K steps as K launches of the per-step kernel (what a policy-in-the-loop user gets)
     env.set_unfused_rollout(True)
@@ -349,21 +378,23 @@ def main():
         host_async_us = t_async * 1e6 / n_host
 
     red_dev = torch.device("cpu") if rehearse else dev
-    stats = torch.tensor([dt, dt_unfused, dt_events or 0.0, gather_ms or 0.0], device=red_dev, dtype=torch.float64)
+    dt_median = sorted(repeats)[len(repeats) // 2]
+    stats = torch.tensor([dt, dt_unfused, dt_events or 0.0, gather_ms or 0.0, dt_median], device=red_dev, dtype=torch.float64)
     k_last = K - (K - 1) // chunk * chunk  # steps in the last chunk, whose outputs are still in the buffers
     n_done = (done[:k_last].sum(dtype=torch.float64) * (K / k_last)).reshape(1).to(red_dev)
     ranks_info = None
     if world > 1:
         # what every rank saw: its clock for the timed region, its device -- so that the line shows N ranks on N devices
         mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index),
-                "ms_per_step": dt * 1e3 / K, "ms_per_step_median": sorted(repeats)[len(repeats) // 2] * 1e3 / K,
+                "ms_per_step": sorted(repeats)[len(repeats) // 2] * 1e3 / K, "ms_per_step_first_region": dt * 1e3 / K,
                 "kernel_avg_us": (kern_ms * 1e3 / launches) if launches else None}
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, mine)
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(n_done, op=dist.ReduceOp.SUM)
-    dt_max, dt_unfused, dt_events = float(stats[0]), float(stats[1]), (float(stats[2]) or None)
+    dt_first, dt_unfused, dt_events = float(stats[0]), float(stats[1]), (float(stats[2]) or None)
     gather_ms = float(stats[3]) or None
+    dt_max = float(stats[4])  # max over ranks of each rank's median region
 
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(args.env)
@@ -395,8 +426,18 @@ def main():
                                "algorithmic_bytes_per_env_step": bytes_per,
                                "algorithmic_bytes_per_launch": steps_per_launch * B * bytes_per}
             out["value_with_dispatch_events"] = world * B * K / dt_events
+        out["value_is"] = f"median of the {len(repeats)} timed regions (max over ranks); value_first_region is the first one"
+        out["value_first_region"] = world * B * K / dt_first
+        out["ms_per_step_first_region"] = dt_first * 1e3 / K
         out["ms_per_step_repeats"] = [r * 1e3 / K for r in repeats]  # rank 0's clock
         out["ms_per_step_median"] = sorted(out["ms_per_step_repeats"])[len(repeats) // 2]
+        if tobs_ms is not None:  # the same launch with terminal observations (TOBS kernel variant)
+            out["with_terminal_observations"] = {
+                "ms_per_step": tobs_ms / K, "value": B * K / (tobs_ms * 1e-3), "unit": "env-steps/s",
+                "kernel": kernel_name.replace("false>", "true>") if "pair_rollout" in kernel_name and kernel_name.startswith("goal") else kernel_name,
+                "kernel_avg_us": tobs_kernel_us, "records_per_launch": tobs_records,
+                "what": "sg_rollout_device_terminal: the same K steps in one launch, plus one record (step, env, last observation) per "
+                        "finished env-step -- what SpaceshipEnv.step returns with done=True (spaceship_env.py:75-78)"}
         out["value_one_launch_per_step"] = world * B * K / dt_unfused
         out["ms_per_step_one_launch_per_step"] = dt_unfused * 1e3 / K
         if graph_ms is not None:  # the same launches replayed from one hipGraph (wall per step)

@@ -143,9 +143,14 @@ int sg_step_device(sg_env *env, const void *actions_dev, float *obs_dev, float *
  *                  not finish read NaN).
  *   sg_step_end    waits for that step and returns pointers into its result block: obs [num_envs, obs_dim], reward, done,
  *                  truncated as in sg_step, terminal_obs or NULL (any out pointer may be NULL).  The handle alternates
- *                  between two blocks: the pointers stay valid until the sg_step_end after next, so the results of step t can
- *                  be read while step t + 1 is in flight.
+ *                  between two blocks: the pointers stay valid until the sg_step_begin after next -- the results of step t can
+ *                  be read while step t + 1 is in flight, and the kernel enqueued by the sg_step_begin of step t + 2 writes
+ *                  them again (it stores into the block while it runs).
  * One step may be in flight per handle; any other call on the handle between the two is ordered behind the step. */
+/* (The two result blocks are allocated by the first sg_step_begin -- callers of the device-pointer entry points never pay for
+ *  them; where device-mapped page-locked memory of that size cannot be had the handle falls back to a device block and copies.
+ *  Whether `actions_host` is page-locked is asked on every call.  If sg_step_end fails the step is no longer in flight: the
+ *  handle accepts the next sg_step_begin.) */
 int sg_step_begin(sg_env *env, const void *actions_host, int32_t want_terminal_obs);
 int sg_step_end(sg_env *env, const float **obs, const float **reward, const uint8_t **done, const uint8_t **truncated,
                 const float **terminal_obs);
@@ -189,6 +194,8 @@ int sg_check_status(sg_env *env);
 typedef struct sg_counters {
     uint64_t env_steps, episodes_finished, truncations, goal_hits;
 } sg_counters;
+/* (All four are counted on the device by the work the calls enqueue, so a replayed hipGraph of *_device calls counts as
+ *  well; switching the counters on or off after a graph was captured does not change that graph.) */
 int sg_set_counters(sg_env *env, int32_t on);                              /* switching (on or off) zeroes the counters */
 int sg_get_counters(sg_env *env, sg_counters *out, int32_t reset);         /* waits for the enqueued work first */
 
@@ -237,7 +244,8 @@ int sg_get_profile(sg_env *env, int64_t *launches, double *total_ms, double *min
  * steps on this handle; valid until the next call on the handle. */
 const char *sg_rollout_kernel(sg_env *env, int32_t n_steps);
 
-/* The HIP stream the host-buffer calls run on (hipStream_t), for callers that want to order work after it. */
+/* The HIP stream the host-buffer calls run on (hipStream_t), for callers that want to order work after it.  Created by
+ * sg_create, destroyed by sg_destroy: the value is valid for the lifetime of the handle and must not be destroyed by the caller. */
 void *sg_stream(const sg_env *env);
 
 const char *sg_version(void);

@@ -5,5 +5,6 @@ hand-written HIP kernels behind the C ABI in include/spacegym.h.  There is no CP
 """
 from .registration import ENV_SPECS, register_with_gym  # noqa: F401
 from .vector_env import SpaceGymVectorEnv, StepInfo, make_vec, make_vec_from_class  # noqa: F401
+from .multi_device import MultiDeviceVectorEnv  # noqa: F401
 
-__all__ = ["make_vec", "make_vec_from_class", "SpaceGymVectorEnv", "StepInfo", "ENV_SPECS", "register_with_gym"]
+__all__ = ["make_vec", "make_vec_from_class", "SpaceGymVectorEnv", "MultiDeviceVectorEnv", "StepInfo", "ENV_SPECS", "register_with_gym"]

@@ -33,7 +33,8 @@ class SpaceGymVectorEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, env_id, num_envs, device=0, seed=0, env_index_base=0, max_episode_steps=None, auto_reset=True,
-                 validate_actions=True, terminal_observation=True, copy=True, steering=None, env_kwargs=None, from_class=False):
+                 validate_actions=True, terminal_observation=True, copy=True, steering=None, env_kwargs=None, from_class=False,
+                 _handle=None):
         """steering: "velocity" (ship_steering=1, what every registered id uses) or "acceleration" (ship_steering=0, the
         constructor default of the reference classes: omega is a state, the thruster a torque); None: what env_kwargs say.
         env_kwargs: keyword arguments of the reference's constructor (GoalEnv.__init__ goal.py:18-31, KeplerEnv.__init__
@@ -73,9 +74,13 @@ class SpaceGymVectorEnv:
         cfg = _native.SgConfig(env_id=env_id.encode(), num_envs=self.num_envs, seed=int(seed),
                                env_index_base=int(env_index_base), max_episode_steps=int(max_episode_steps or 0),
                                auto_reset=int(bool(auto_reset)), steering={"velocity": 0, "acceleration": 1}[steering])
-        h = C.c_void_p()
-        rc = self._lib.sg_create_ex(C.byref(cfg), C.byref(params), self.device, C.byref(h))
-        _native.check(self._lib, None, rc, "sg_create_ex")
+        self._cfg, self._params = cfg, params
+        if _handle is None:
+            h = C.c_void_p()
+            rc = self._lib.sg_create_ex(C.byref(cfg), C.byref(params), self.device, C.byref(h))
+            _native.check(self._lib, None, rc, "sg_create_ex")
+        else:  # a handle made by sg_create_sharded_ex (MultiDeviceVectorEnv): `num_envs`, `device`, `env_index_base` describe it
+            h = _handle
         self._h = h
         assert self._lib.sg_obs_dim(h) == self.obs_dim
         B, D = self.num_envs, self.obs_dim
@@ -206,9 +211,10 @@ class SpaceGymVectorEnv:
     def step_wait(self):
         if not self._pending:
             raise RuntimeError("step_wait() without step_async()")
-        self._pending = False
         p = [C.c_void_p() for _ in range(5)]
-        self._ck(self._lib.sg_step_end(self._h, *[C.byref(x) for x in p]), "sg_step_end")
+        rc = self._lib.sg_step_end(self._h, *[C.byref(x) for x in p])
+        self._pending = False  # (the native side has given the step up as well if the wait failed)
+        self._ck(rc, "sg_step_end")
         obs, rew, done, trunc, tobs = self._block_views([x.value for x in p])
         info = StepInfo({"TimeLimit.truncated": trunc.view(np.bool_) if not self.copy else trunc.astype(bool)})
         if tobs is not None:
@@ -457,7 +463,12 @@ def make_vec(env_id, num_envs=1, **kwargs):
     survival_reward_scale, n_planets, ship_steering, ship_moi, max_engine_force; KeplerEnv.__init__ kepler.py:189-203: randomize,
     ref_orbit_a, ref_orbit_eccentricity, ref_orbit_angle, numerator_C, rad_penalty_C, act_penalty_C, step_size, ship_steering,
     ship_moi, max_engine_force) override what the id is registered with; the engine's own keywords (device, seed, ...) are
-    SpaceGymVectorEnv's."""
+    SpaceGymVectorEnv's.  devices=[...] cuts the batch into one block per listed GPU, driven by this one process
+    (MultiDeviceVectorEnv)."""
+    devices = kwargs.pop("devices", None)
+    if devices is not None:  # one VectorEnv over several GPUs, driven by this process (space_gym_amd/multi_device.py)
+        from .multi_device import MultiDeviceVectorEnv
+        return MultiDeviceVectorEnv(env_id, num_envs, devices, **kwargs)
     engine = {k: kwargs.pop(k) for k in list(kwargs) if k in _ENGINE_KWARGS}
     if kwargs:
         engine["env_kwargs"] = {**(engine.get("env_kwargs") or {}), **kwargs}

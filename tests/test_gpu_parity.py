@@ -666,7 +666,7 @@ def test_constructor_kwargs_match_reference_golden(name):
     env.close()
     # the same parameters through K-step rollouts (wave-pair kernels) against one-launch-per-step: bit-identical
     import torch
-    n, K = 4096, 24
+    n, K = 4096, 48
     envs = [sg.make_vec(str(d["env_id"]), n, device=0, seed=3, from_class=True, max_episode_steps=40, **kw) for _ in range(2)]
     a = torch.rand((K, n, 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 2 - 1
     outs = []

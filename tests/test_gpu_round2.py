@@ -508,3 +508,69 @@ def test_actions_out_of_range_are_rejected_by_default():
     obs, rew, done, info = env.step(a)  # clamped into [-1, 1] on the device
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     env.close()
+
+
+def test_multi_device_front_end_equals_one_handle():
+    """MultiDeviceVectorEnv (single process, one native handle per listed device through sg_create_sharded_ex): three blocks --
+    all on device 0 here, the only GPU of the box -- are the same envs as one handle of the whole batch, bit for bit: reset,
+    steps (per-block streams, results gathered into the root's arrays) and K-step rollouts with one gather per K steps."""
+    import torch
+    import space_gym_amd as sg
+    n, K = 5000, 12  # ragged blocks: 1667 + 1667 + 1666
+    one = sg.make_vec("GoalContinuous3P-v0", n, device=0, seed=9, max_episode_steps=30, terminal_observation=False)
+    multi = sg.make_vec("GoalContinuous3P-v0", n, devices=[0, 0, 0], seed=9, max_episode_steps=30, copy=False)
+    assert [hi - lo for lo, hi in multi.bounds] == [1667, 1667, 1666] and len(multi.shards) == 3
+    o1 = one.reset_torch().clone(); om = multi.reset_torch()
+    assert torch.equal(o1, om)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    seen = set()
+    for t in range(40):
+        a = torch.rand((n, 2), device="cuda", generator=g) * 2 - 1
+        r1 = [x.clone() for x in one.step_torch(a)]
+        rm = multi.step_torch(a)
+        seen.add(rm[0].data_ptr())
+        for x, y in zip(r1, rm):
+            assert torch.equal(x, y)
+    assert len(seen) == 2  # copy=False: two result sets that alternate
+    a = torch.rand((K, n, 2), device="cuda", generator=g) * 2 - 1
+    o = torch.empty((K, n, one.obs_dim), device="cuda"); r = torch.empty((K, n), device="cuda")
+    d = torch.empty((K, n), dtype=torch.uint8, device="cuda"); tr = torch.empty_like(d)
+    one.rollout_torch(a, o, r, d, tr)
+    mo, mr, md, mt = multi.rollout_torch(a)
+    assert torch.equal(o, mo) and torch.equal(r, mr) and torch.equal(d, md) and torch.equal(tr, mt)
+    assert int(d.sum()) > 100  # episodes ended and restarted
+    s1, sm = one.get_state(), multi.get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], sm[k])
+    # NumPy convenience path
+    obs, rew, done, info = multi.step(a[0].cpu().numpy())
+    o1, r1, d1, i1 = one.step(a[0].cpu().numpy())
+    assert np.array_equal(obs, o1) and np.array_equal(rew, r1) and np.array_equal(done, d1)
+    multi.check_status(); one.close(); multi.close()
+    # a discrete id with constructor kwargs through the same front end
+    m2 = sg.make_vec("GoalDiscrete3-v0", 777, devices=[0, 0], seed=2, max_engine_force=0.8)
+    o2 = sg.make_vec("GoalDiscrete3-v0", 777, device=0, seed=2, max_engine_force=0.8, terminal_observation=False)
+    assert torch.equal(m2.reset_torch(), o2.reset_torch())
+    ai = torch.randint(0, 6, (777,), device="cuda", dtype=torch.int32, generator=g)
+    for x, y in zip(m2.step_torch(ai), o2.step_torch(ai)):
+        assert torch.equal(x, y)
+    m2.close(); o2.close()
+
+
+def test_step_end_pointers_stay_valid_until_the_begin_after_next():
+    """include/spacegym.h: the result block of step t is written again by the kernel enqueued by sg_step_begin of step t + 2
+    (not before): its contents are intact after step t + 1 has completed."""
+    import space_gym_amd as sg
+    n = 4096
+    env = sg.make_vec("GoalContinuous2P-v0", n, device=0, seed=1, copy=False)
+    env.reset()
+    rng = np.random.default_rng(0)
+    a = [rng.uniform(-1, 1, (n, 2)).astype(np.float32) for _ in range(3)]
+    env.step_async(a[0]); obs0, rew0, done0, _ = env.step_wait()
+    keep = (obs0.copy(), rew0.copy(), done0.copy())
+    env.step_async(a[1]); obs1, rew1, done1, _ = env.step_wait()
+    assert obs1.ctypes.data != obs0.ctypes.data  # the other block
+    assert np.array_equal(obs0, keep[0]) and np.array_equal(rew0, keep[1]) and np.array_equal(done0, keep[2])  # step t intact after step t + 1
+    env.step_async(a[2]); obs2, _, _, _ = env.step_wait()
+    assert obs2.ctypes.data == obs0.ctypes.data and not np.array_equal(obs2, keep[0])  # written again by step t + 2
+    env.close()

@@ -197,3 +197,32 @@ def test_sg_params_layout_matches_the_header():
         ctype, rest = decl.split(None, 1)
         names += [n.strip() for n in rest.split(",")]
     assert names == [f for f, _ in _native.SgParams._fields_], names
+
+
+def test_register_with_gym_against_a_stub_module(monkeypatch):
+    """register_with_gym() against a stand-in `gym` module (no gym / gymnasium in the image): every served id is registered once
+    under <name>Vec-v0 with the vector entry point and the id as kwarg, without a TimeLimit of gym's own (the engine counts
+    the steps itself); a failing register() call does not stop the others; without either module nothing happens."""
+    import sys
+    import types
+    from space_gym_amd import registration
+    calls = []
+
+    def register(id, entry_point, kwargs=None, max_episode_steps=None, **rest):
+        if id == "KeplerDiscreteVec-v0":
+            raise RuntimeError("already registered")  # e.g. a second call
+        calls.append((id, entry_point, kwargs, max_episode_steps))
+    monkeypatch.setitem(sys.modules, "gym", types.SimpleNamespace(register=register))
+    monkeypatch.setitem(sys.modules, "gymnasium", None)  # import gymnasium -> ImportError
+    done = registration.register_with_gym()
+    ids = [c[0] for c in calls]
+    assert sorted(ids) == sorted(k.replace("-v0", "Vec-v0") for k in registration.ENV_SPECS if k != "KeplerDiscrete-v0")
+    assert all(c[1] == "space_gym_amd.vector_env:make_vec" and c[3] is None for c in calls)
+    assert all(c[2] == dict(env_id=c[0].replace("Vec-v0", "-v0")) for c in calls)
+    assert done == [("gym", i) for i in ids]
+    # the entry point is what gym.make would call: make_vec(env_id=..., **user kwargs)
+    import importlib
+    mod, fn = calls[0][1].split(":")
+    assert callable(getattr(importlib.import_module(mod), fn))
+    monkeypatch.setitem(sys.modules, "gym", None)
+    assert registration.register_with_gym() == []

@@ -33,6 +33,12 @@ def measure(env_id, B, plan, kw, n=200):
     for _ in range(4):
         env.rollout_torch(acts, obs, rew, done, trunc)
     torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(max(1, n // K)):
+        env.rollout_torch(acts, obs, rew, done, trunc)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e6 / (max(1, n // K) * K)
     env.set_profiling(True)
     for _ in range(max(1, n // K)):
         env.rollout_torch(acts, obs, rew, done, trunc)
@@ -43,8 +49,8 @@ def measure(env_id, B, plan, kw, n=200):
     env.close()
     bytes_per = (113 + 16 * env.n_planets) if env.spec["family"] == "goal" else 109
     avg = tot * 1e3 / cnt
-    print("%-22s B=%-8d %-34s n=%4d avg %7.2f us  min %7.2f  max %7.2f   frac %.3f   %.2f G env-steps/s" % (
-        env_id, B, name, cnt, avg, mn * 1e3, mx * 1e3, B * bytes_per / (avg * 1e-6) / 8e12, B / (avg * 1e-6) / 1e9), flush=True)
+    print("%-22s B=%-8d %-34s n=%4d avg %7.2f us  min %7.2f  max %7.2f   frac %.3f   %.2f G env-steps/s   wall %.2f us/step" % (
+        env_id, B, name, cnt, avg, mn * 1e3, mx * 1e3, B * bytes_per / (avg * 1e-6) / 8e12, B / (avg * 1e-6) / 1e9, wall), flush=True)
 
 
 def main():
