@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--env", default="GoalContinuous3P-v0")
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--steering", choices=["velocity", "acceleration"], default="velocity",
+                    help="ship_steering of the reference's constructor: 1 (velocity, every registered id) or 0 (acceleration)")
     ap.add_argument("--action-ring", type=int, default=0, help="distinct pre-generated action blocks (0: one per step)")
     ap.add_argument("--action-source", choices=["torch", "engine"], default="torch",
                     help="who draws the U(-1,1) action tape: torch.rand (per-rank generator) or sg_random_actions_device")
@@ -170,7 +172,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
-    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B, copy=False, terminal_observation=False, validate_actions=False)
+    env = sg.make_vec(args.env, B, device=dev_index, seed=args.seed, env_index_base=rank * B, copy=False, terminal_observation=False, validate_actions=False,
+                      steering=args.steering)
     D = env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
@@ -407,7 +410,7 @@ def main():
                                    f"({ring} distinct blocks), auto-reset on (termination or 500-step truncation), "
                                    f"the {K} steps in {-(-K // chunk)} sg_rollout_device call(s) (one launch of "
                                    f"{kernel_name} each, env state in registers), outputs to a [steps, B, ...] rollout buffer in HBM",
-                       "env_id": args.env, "batch_per_gpu": B, "global_batch": world * B, "obs_dim": D,
+                       "env_id": args.env, "steering": args.steering, "batch_per_gpu": B, "global_batch": world * B, "obs_dim": D,
                        "parallelism": f"env-sharded x{world}, no data-path collective",
                        "episodes_finished_per_step": float(n_done.item()) / K, "preroll_steps": args.preroll},
         }

@@ -588,6 +588,23 @@ def test_integration_md_stub_runs_as_written():
     assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
     assert np.array_equal(i1["TimeLimit.truncated"], i2["TimeLimit.truncated"])
     stub.close(); ours.close()
+    # the constructor-kwargs block of the same section, as written: sg_params_init + sg_create_ex
+    import ctypes as C
+    block2 = re.search(r"```python\n(class _Params\(C.Structure\).*?)```", md, re.S).group(1)
+    exec(compile(block2, "INTEGRATION.md", "exec"), ns)
+    lib = C.CDLL(_native.LIB_PATH)
+    cfg = ns["_Cfg"](b"KeplerCircleOrbit-v0", 256, 3, 0, 0, 1, 0)
+    kw = dict(ref_orbit_a=1.5, ref_orbit_eccentricity=0.3, ref_orbit_angle=2.0, step_size=0.1, max_engine_force=0.6)
+    h = ns["create"](lib, cfg, 0, **kw)
+    got = ns["_Params"]()
+    lib.sg_get_params.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.sg_get_params(h, C.byref(got)) == 0
+    for k, v in kw.items():
+        assert abs(getattr(got, k) - v) < 1e-6, (k, getattr(got, k))
+    lib.sg_destroy.argtypes = [C.c_void_p]
+    lib.sg_destroy(h)
+    with pytest.raises(RuntimeError, match="GoalEnv keyword"):
+        ns["create"](lib, cfg, 0, danger_zone=0.3)  # a GoalEnv keyword for a Kepler id is refused
 
 
 def test_vector_field_matches_reference():
