@@ -4,6 +4,7 @@ steady state (envs pre-rolled to their stationary mix of episode ages).  The slo
 fixed cost of a launch (workgroup start, state load / store, pipeline fill and drain of the pilot + finisher pair).
 
     python tools/gpu_ksweep.py [env_id] [batch] [K,K,...]
+SG_KSWEEP_TOBS=1: with a terminal-observation list (sg_rollout_device_terminal).
 """
 import json
 import os
@@ -35,17 +36,21 @@ def main():
         env.rollout_torch(acts[:200], obs[:200], rew[:200], done[:200], trunc[:200])
     torch.cuda.synchronize()
     rows = []
+    tobs = bool(os.environ.get("SG_KSWEEP_TOBS"))
     for K in Ks:
+        term = dict(terminal=env.terminal_list_torch(max(4096, K * B // 8))) if tobs else {}
         for _ in range(3):
-            env.rollout_torch(acts[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+            env.rollout_torch(acts[:K], obs[:K], rew[:K], done[:K], trunc[:K], **term)
         torch.cuda.synchronize()
         env.set_profiling(True)
         for _ in range(reps):
-            env.rollout_torch(acts[:K], obs[:K], rew[:K], done[:K], trunc[:K])
+            env.rollout_torch(acts[:K], obs[:K], rew[:K], done[:K], trunc[:K], **term)
         torch.cuda.synchronize()
         n, tot, mn, mx = env.get_profile()
         env.set_profiling(False)
-        rows.append(dict(K=K, kernel=env.rollout_kernel(K), launches=n, avg_us=tot * 1e3 / n, min_us=mn * 1e3, max_us=mx * 1e3,
+        if tobs:
+            env.terminal_records(term["terminal"])  # (raises on overflow)
+        rows.append(dict(K=K, kernel=env.rollout_kernel(K) + (" +terminal list" if tobs else ""), launches=n, avg_us=tot * 1e3 / n, min_us=mn * 1e3, max_us=mx * 1e3,
                          us_per_step=tot * 1e3 / n / K))
         print("K=%4d  %-40s avg %8.2f us  min %8.2f  max %8.2f   %.3f us/step" % (
             K, rows[-1]["kernel"], rows[-1]["avg_us"], rows[-1]["min_us"], rows[-1]["max_us"], rows[-1]["us_per_step"]), flush=True)
