@@ -56,13 +56,9 @@ def main():
         names2 = ["inputs wait", "stores + next loads issued", "first step", "reward + observation", "records + lists", "loop back"]
         print("mean cycles per pass over all passes (%.1f passes per wave): " % n_pass + ", ".join("%s %.0f" % (n, acc[:, k].mean() / n_pass) for k, n in enumerate(names2)) +
               "; sum %.0f" % (acc[:, :6].sum(1).mean() / n_pass))
-    # where the workgroups ran and how long they lived (slot 12: HW_ID | XCC_ID << 32; slot 11: records | restarts << 16 | resamples << 32 of the wave)
-    hw = buf.reshape(WAVES, SLOTS)[:len(st), 12]
+    # how long the workgroups lived (slot 11: records | restarts << 16 | resamples << 32 the wave had gathered when it reached the barrier)
     val = buf.reshape(WAVES, SLOTS)[:len(st), 11]
     n_wg = len(st) // 4
-    xcc = ((hw >> np.uint64(32)) & np.uint64(0xf)).astype(int).reshape(n_wg, 4)[:, 0]
-    lo = (hw & np.uint64(0xffffffff)).astype(np.int64).reshape(n_wg, 4)
-    simd = (lo >> 4) & 3; cu = (lo[:, 0] >> 8) & 15; sh = (lo[:, 0] >> 12) & 1; se = (lo[:, 0] >> 13) & 7
     life = (st[:, 7].reshape(n_wg, 4).max(1) - st[:, 6].reshape(n_wg, 4).min(1)) / 100
     passes = (st[:, 3].reshape(n_wg, 4).max(1) - st[:, 0].reshape(n_wg, 4).min(1))  # entry -> last wave through with its subtiles
     tail = (st[:, 5].reshape(n_wg, 4).max(1) - st[:, 3].reshape(n_wg, 4).max(1))
@@ -72,32 +68,6 @@ def main():
         life.mean(), np.median(life), np.percentile(life, 95), life.max(), passes.mean(), np.percentile(passes, 95), passes.max(), tail.mean(), np.percentile(tail, 95), tail.max()))
     print("records per workgroup mean %.1f max %d; restarts mean %.1f max %d; corr(lifetime, records) %.2f corr(lifetime, passes) %.2f corr(lifetime, tail) %.2f" % (
         recs.mean(), recs.max(), rst.mean(), rst.max(), np.corrcoef(life, recs)[0, 1], np.corrcoef(life, passes)[0, 1], np.corrcoef(life, tail)[0, 1]))
-    print("simd of waves 0..3 of workgroup 0..3:", simd[:4].tolist())
-    print("raw HW_ID / XCC_ID of wave 0 of workgroups 0..11:", ["%08x/%08x" % (int(h) & 0xffffffff, int(h) >> 32) for h in hw.reshape(n_wg, 4)[:12, 0]])
-    print("raw slot 11 of workgroup 0..3:", ["%x" % int(v) for v in val[:16]])
-    grp = (hw.reshape(n_wg, 4)[:, 0] & np.uint64(0xffffffffffffff00))
-    ug, inv, gc = np.unique(grp, return_inverse=True, return_counts=True)
-    print("groups by (XCC_ID, HW_ID without wave/simd/pipe): %d; sizes %s" % (len(ug), dict(zip(*np.unique(gc, return_counts=True)))))
-    two = [np.flatnonzero(inv == g) for g in range(len(ug)) if gc[g] == 2]
-    if two:
-        d = np.array([abs(passes[a] - passes[b]) for a, b in two]); m = np.array([(passes[a] + passes[b]) / 2 for a, b in two])
-        print("pairs of workgroups in one group: |difference of passes| mean %.0f p95 %.0f; pair means: mean %.0f p95 %.0f max %.0f" % (
-            d.mean(), np.percentile(d, 95), m.mean(), np.percentile(m, 95), m.max()))
-    for x in range(8):
-        m = xcc == x
-        if m.any():
-            print("  xcc %d: %3d workgroups, lifetime mean %.2f max %.2f, passes mean %.0f, tail mean %.0f" % (x, m.sum(), life[m].mean(), life[m].max(), passes[m].mean(), tail[m].mean()))
-    key = xcc * 1000 + se * 100 + sh * 50 + cu
-    uniq, cnt = np.unique(key, return_counts=True)
-    print("CUs used: %d; workgroups per CU: %s" % (len(uniq), dict(zip(*np.unique(cnt, return_counts=True)))))
-    per_cu = dict(zip(uniq, cnt))
-    share = np.array([per_cu[k] for k in key])
-    for k in np.unique(share):
-        print("  workgroups on a CU with %d workgroup(s): %d, lifetime mean %.2f max %.2f" % (k, (share == k).sum(), life[share == k].mean(), life[share == k].max()))
-    order = np.argsort(-life)[:12]
-    print("slowest workgroups (index, xcc, se, sh, cu, lifetime us, passes, tail, records):")
-    for j in order:
-        print("   %4d  x%d se%d sh%d cu%2d  %.2f  %6.0f %6.0f  %3d" % (j, xcc[j], se[j], sh[j], cu[j], life[j], passes[j], tail[j], recs[j]))
     env.close()
 
 
