@@ -138,3 +138,40 @@ def test_step_kernel_lists_overflow_into_wave_local_flush(env_id, auto_reset, mo
                      None if g is None else g[:k].astype(np.float64))
         assert np.array_equal(x[2][:k], ref["done"].astype(bool))
         check_against(x[0][:k], x[1][:k], x[2][:k], x[4]["ship"][:k], ref["state1"], ref["obs"], ref["reward"], ref["done"])
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 257, 1000])
+@pytest.mark.parametrize("env_id", ["GoalContinuous3P-v0", "KeplerRandomOrbits-v0", "GoalDiscrete3-v0"])
+def test_step_kernel_on_tiny_and_ragged_batches(env_id, n, monkeypatch):
+    """fewer envs than a wave, a subtile with one env, waves of a workgroup without a subtile: the one-wave step kernel (lanes
+    and waves past the batch load env 0 by LDS-DMA and store nothing) against the wave-pair step kernel, bit for bit"""
+    import torch
+    K = 40
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    recs = []
+    for kernel in ("single", "pair"):
+        monkeypatch.setenv("SPACEGYM_STEP_KERNEL", kernel)
+        env = make(env_id, n, seed=3, max_episode_steps=7)
+        gen.manual_seed(n)
+        if env.discrete:
+            a = torch.randint(0, 6, (K, n), device="cuda", generator=gen, dtype=torch.int32)
+        else:
+            a = torch.rand((K, n, 2), device="cuda", generator=gen) * 2 - 1
+        env.reset_torch()
+        rec = []
+        for t in range(K):
+            tobs = torch.zeros((n, env.obs_dim), device="cuda")
+            obs, rew, done, trunc = env.step_torch(a[t], terminal_obs=tobs)
+            rec.append((obs.clone(), rew.clone(), done.clone(), trunc.clone(), torch.where(done.bool()[:, None], tobs, torch.zeros_like(tobs))))
+        torch.cuda.synchronize()
+        env.check_status()
+        recs.append((rec, env.get_state()))
+        env.close()
+    (r1, s1), (r2, s2) = recs
+    assert sum(int(x[2].sum()) for x in r1) >= n  # every env finished an episode (truncation at 7 steps at the latest)
+    for t, (x, y) in enumerate(zip(r1, r2)):
+        for f, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), f"step {t} field {f}"
+    for k in ("ship", "goal", "elapsed", "planets"):
+        if s1[k] is not None:
+            assert np.array_equal(s1[k], s2[k]), k
